@@ -1,0 +1,202 @@
+/*
+ * o2m_hip.h -- C ABI of libo2m_hip.so: the MI355X (gfx950) kernels behind the one-to-many
+ * GAN training step.
+ *
+ * The reference (struan-robertson/one-to-many-gan) has no FFI layer of its own: its
+ * "operator API" is torch.nn.functional.  Every entry point below therefore names the
+ * torch call site in the reference that it replaces (paths relative to the reference
+ * tree).  The Python host (one_to_many_gan_amd/_hip.py) binds these with ctypes; see
+ * INTEGRATION.md for the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - Plain pointers and sizes only; no torch types.  All pointers are DEVICE pointers
+ *    (HBM), owned by the caller for the duration of the enqueue.  Nothing is allocated,
+ *    nothing is synchronised, no global mutable state: every call only enqueues work on
+ *    `stream` (a hipStream_t passed as void*), so calls are re-entrant (autograd worker
+ *    threads) and capturable into a hipGraph.
+ *  - Return value: 0 on success, otherwise a hipError_t (launch failure) or
+ *    O2M_ERR_* (argument rejected before any launch).
+ *  - Activation tensors are NHWC ("channels last"), C a multiple of 8, element type
+ *    `dtype`: O2M_BF16 (bf16 storage, one bf16 MFMA per product, fp32 accumulate) or
+ *    O2M_F32 (fp32 storage; the MFMA runs the bf16x3 split hi*hi + hi*lo + lo*hi with
+ *    fp32 accumulate, ~2^-16 relative error per product: the parity mode).
+ *  - Per-sample / per-channel vectors (scales, biases, statistics) are always fp32.
+ */
+#ifndef O2M_HIP_H
+#define O2M_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define O2M_BF16 0
+#define O2M_F32 1
+
+#define O2M_ACT_NONE 0
+#define O2M_ACT_RELU 1
+#define O2M_ACT_LRELU 2 /* negative slope 0.2 */
+#define O2M_ACT_TANH 3
+
+#define O2M_PAD_ZERO 0
+#define O2M_PAD_REFLECT 1
+
+#define O2M_ERR_BAD_ARG 10001
+#define O2M_ERR_UNSUPPORTED 10002
+
+/* ABI version; bumped whenever a struct or signature changes. */
+int o2m_abi_version(void);
+
+/* ------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution on MFMA (v_mfma_f32_32x32x16_bf16), stride 1, dilation 1.
+ *   y[b,oy,ox,o] = act( out_scale[b,o] * sum_{kh,kw,i} w[o,kh,kw,i] *
+ *                        (in_scale[b,i] * xpad[b,oy+kh-pad,ox+kw-pad,i]) + bias[o] )
+ *                  + residual[b,oy,ox,o]
+ * Replaces F.conv2d at layers.py:84-100 (EqualisedConv2d), the grouped per-sample
+ * F.conv2d of Conv2dWeightModulate at layers.py:145-182 (as activation modulation:
+ * in_scale = style s[b,i], out_scale = demodulation rsqrt(...)[b,o], shared weights),
+ * the ReflectionPad2d feeding it (blocks.py:21,25,49,54; builder.py:162,202) via
+ * pad_mode, and the activation behind it (builder.py:196,204,270,301).  The same entry
+ * computes the data gradient ("convT2d") when given the flipped/transposed filter and
+ * pad' = K-1-pad.
+ * Ho = H + 2*pad - KH + 1 (likewise Wo).  Ci % 8 == 0, Co % 8 == 0.
+ * w layout: [Co][KH][KW][Ci] (reduction index contiguous), element type `dtype`.
+ */
+typedef struct {
+  const void* x;          /* [B][H][W][Ci]                       */
+  const void* w;          /* [Co][KH][KW][Ci]                    */
+  void* y;                /* [B][Ho][Wo][Co]                     */
+  const float* in_scale;  /* [B][Ci] or NULL                     */
+  const float* out_scale; /* [B][Co] or NULL                     */
+  const float* bias;      /* [Co]    or NULL                     */
+  const void* residual;   /* [B][Ho][Wo][Co] or NULL             */
+  int32_t B, H, W, Ci, Co, KH, KW, pad, pad_mode, act, dtype;
+  int32_t reserved[5];
+} o2m_conv_desc;
+int o2m_conv2d_fwd(const o2m_conv_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Weight gradient of the convolution above (the wgrad half of aten::convolution_backward
+ * for the same call sites), split over the B*Ho*Wo reduction, fp32 atomics into dw:
+ *   dw[o,kh,kw,i] += sum_{b,oy,ox} (gy_scale[b,o]*gy[b,oy,ox,o]) *
+ *                                   (in_scale[b,i]*xpad[b,oy+kh-pad,ox+kw-pad,i])
+ * dw is fp32 [Co][KH][KW][Ci] and must be zeroed (or hold the running sum) by the caller.
+ */
+typedef struct {
+  const void* x;         /* [B][H][W][Ci]      */
+  const void* gy;        /* [B][Ho][Wo][Co]    */
+  float* dw;             /* [Co][KH][KW][Ci]   */
+  const float* in_scale; /* [B][Ci] or NULL    */
+  const float* gy_scale; /* [B][Co] or NULL    */
+  int32_t B, H, W, Ci, Co, KH, KW, pad, pad_mode, dtype;
+  int32_t splits;        /* >=1: number of slices of the pixel reduction; 0 = auto */
+  int32_t reserved[5];
+} o2m_wgrad_desc;
+int o2m_conv2d_wgrad(const o2m_wgrad_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Backward of the fused epilogue: gu = g * act'(y), plus the per-(b,c) sums the
+ * modulated conv and the bias need:
+ *   sums[b,c,0] = sum_p gu ,  sums[b,c,1] = sum_p gu * (y - residual)
+ * (second sum gives d loss / d out_scale = sums1 / out_scale for act in {none, relu}).
+ * sums is fp32 [B][C][2], zeroed by the caller (accumulated with atomics).
+ * Replaces the ReLU/LeakyReLU/Tanh backward and the bias reduction of
+ * convolution_backward.  `y` is the forward OUTPUT (post-activation).
+ */
+int o2m_act_bwd_reduce(const void* g, const void* y, const void* residual, void* gu,
+                       float* sums, int32_t B, int32_t P, int32_t C, int32_t act,
+                       int32_t dtype, void* stream);
+
+/* Backward of ReflectionPad2d fused with the style scale and the style-gradient dot:
+ *   gfold = fold_reflect(gpad)             (pad == 0: identity)
+ *   gx[b,y,x,c]   = gfold[b,y,x,c] * scale[b,c]      (scale NULL: 1)
+ *   dots[b,c]    += sum_{y,x} gfold[b,y,x,c] * x[b,y,x,c]   (dots/x NULL: skipped)
+ * gpad is [B][H+2p][W+2p][C]; gx, x are [B][H][W][C]; dots fp32 [B][C] zeroed by caller.
+ */
+int o2m_fold_scale_dot(const void* gpad, const void* x, const float* scale, void* gx,
+                       float* dots, int32_t B, int32_t H, int32_t W, int32_t C, int32_t pad,
+                       int32_t dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * InstanceNorm2d (eps, biased variance, no affine; builder.py:164,172,273..; blocks.py:23,27)
+ * fused with the activation behind it and the residual add of ResnetBlock (blocks.py:33).
+ *   stats : partial[b,chunk,c,{sum,sumsq}] over pixel chunks (deterministic two-stage),
+ *           then mean_rstd[b,c,{mean,rstd}].
+ *   apply : y = act((x-mean)*rstd) + residual
+ *   bwd   : with xh=(x-mean)*rstd, gh = g*act'(xh):  gx = rstd*(gh - mean_p(gh) - xh*mean_p(gh*xh))
+ * `partial` is caller workspace of o2m_instnorm_ws_floats(B,P,C) floats.
+ */
+size_t o2m_instnorm_ws_floats(int32_t B, int32_t P, int32_t C);
+int o2m_instnorm_stats(const void* x, float* partial, float* mean_rstd, int32_t B, int32_t P,
+                       int32_t C, float eps, int32_t dtype, void* stream);
+int o2m_instnorm_apply(const void* x, const float* mean_rstd, const void* residual, void* y,
+                       int32_t B, int32_t P, int32_t C, int32_t act, int32_t dtype, void* stream);
+int o2m_instnorm_bwd(const void* g, const void* x, const float* mean_rstd, float* partial,
+                     float* gsums, void* gx, int32_t B, int32_t P, int32_t C, int32_t act,
+                     int32_t dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Separable banded resampling: y[b,oy,ox,c] = sum_{ty,tx} wy[oy,ty]*wx[ox,tx] *
+ *                                             x[b, sy[oy]+ty, sx[ox]+tx, c]
+ * One kernel serves Smooth (layers.py:207-214), UpSample = bilinear x2 then blur
+ * (layers.py:223-229), DownSample = blur then bilinear to floor(H/2) (layers.py:241-247,
+ * fractional taps for odd sizes) and the transposes of all three (their backward); the
+ * host composes the 1-D operators (one_to_many_gan_amd/resample.py) and passes the taps.
+ * sy/sx: int32 [Ho]/[Wo] first source index; wy/wx: fp32 [Ho][T]/[Wo][T], zero padded.
+ * Taps must stay in range: 0 <= s[o] and s[o]+T <= source size (host guarantees).
+ */
+int o2m_resample2d(const void* x, void* y, const int32_t* sy, const float* wy,
+                   const int32_t* sx, const float* wx, int32_t B, int32_t H, int32_t W,
+                   int32_t Ho, int32_t Wo, int32_t C, int32_t T, int32_t dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Layout conversion at the public (logical NCHW fp32) boundary.
+ *   pack  : NCHW fp32 [B][C][H][W]  -> NHWC `dtype` [B][H][W][Cp] (channels >= C zeroed)
+ *   unpack: NHWC `dtype` [B][H][W][Cp] -> NCHW fp32 [B][C][H][W]
+ */
+int o2m_pack_nchw(const float* src, void* dst, int32_t B, int32_t C, int32_t H, int32_t W,
+                  int32_t Cp, int32_t dtype, void* stream);
+int o2m_unpack_nhwc(const void* src, float* dst, int32_t B, int32_t C, int32_t H, int32_t W,
+                    int32_t Cp, int32_t dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Loss reductions (F.l1_loss / F.mse_loss at training.py:111-112,178,188,202;
+ * kl_loss_func loss.py:82-92; path_loss_func loss.py:98-111).  All write per-block fp32
+ * partial sums (deterministic; the host adds them) -- no host sync, graph-capturable.
+ *   mode O2M_RED_L1   : sum |a-b|
+ *   mode O2M_RED_SQ   : sum w[b]*(a-b)^2        (b NULL: 0; w NULL: 1)
+ *   mode O2M_RED_MOM  : {sum a, sum a^2}        (two partials per block)
+ * and their elementwise backward:
+ *   O2M_RED_L1 : ga = coef[0]*sign(a-b)
+ *   O2M_RED_SQ : ga = coef[0]*w[b]*(a-b)
+ *   O2M_RED_MOM: ga = coef[0] + coef[1]*a
+ * coef is a DEVICE pointer to fp32 scalars (upstream gradient folded in by the host ops).
+ * n_per_sample = elements per batch sample (H*W*C); partials has o2m_reduce_blocks(n)
+ * entries per output.
+ */
+#define O2M_RED_L1 0
+#define O2M_RED_SQ 1
+#define O2M_RED_MOM 2
+int32_t o2m_reduce_blocks(int64_t n);
+int o2m_reduce_fwd(const void* a, const void* b, const float* w, float* partials, int32_t B,
+                   int64_t n_per_sample, int32_t mode, int32_t dtype, void* stream);
+int o2m_reduce_bwd(const void* a, const void* b, const float* w, const float* coef, void* ga,
+                   int32_t B, int64_t n_per_sample, int32_t mode, int32_t dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Fused Adam over one flat fp32 bucket (torch.optim.Adam at train.py:94-116: no weight
+ * decay, eps 1e-8).  `step` is a DEVICE fp32 scalar holding the 1-based step count (the
+ * host bumps it with a device-side add, so the update is graph-capturable).
+ *   m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g
+ *   p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+ * grad_scale multiplies g first (1/world_size after a sum all-reduce).
+ */
+int o2m_adam_step(float* p, const float* g, float* m, float* v, const float* step, int64_t n,
+                  float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* O2M_HIP_H */

@@ -1,0 +1,205 @@
+"""ctypes binding of libo2m_hip.so (the C ABI declared in include/o2m_hip.h).
+
+There is NO fallback: if the library is missing or a call is made without a GPU tensor the
+import / call raises.  The product path never routes through PyTorch eager kernels for the
+ops declared in the header, and never through the CPU oracle.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libo2m_hip.so")
+
+BF16, F32 = 0, 1
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
+PAD_ZERO, PAD_REFLECT = 0, 1
+RED_L1, RED_SQ, RED_MOM = 0, 1, 2
+ABI_VERSION = 1
+
+_vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("x", _vp), ("w", _vp), ("y", _vp), ("in_scale", _vp), ("out_scale", _vp),
+                ("bias", _vp), ("residual", _vp),
+                ("B", _i32), ("H", _i32), ("W", _i32), ("Ci", _i32), ("Co", _i32), ("KH", _i32),
+                ("KW", _i32), ("pad", _i32), ("pad_mode", _i32), ("act", _i32), ("dtype", _i32),
+                ("reserved", _i32 * 5)]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [("x", _vp), ("gy", _vp), ("dw", _vp), ("in_scale", _vp), ("gy_scale", _vp),
+                ("B", _i32), ("H", _i32), ("W", _i32), ("Ci", _i32), ("Co", _i32), ("KH", _i32),
+                ("KW", _i32), ("pad", _i32), ("pad_mode", _i32), ("dtype", _i32), ("splits", _i32),
+                ("reserved", _i32 * 5)]
+
+
+# name -> (restype, argtypes); mirrors include/o2m_hip.h one for one
+SIGNATURES = {
+    "o2m_abi_version": (_i32, []),
+    "o2m_conv2d_fwd": (_i32, [C.POINTER(ConvDesc), _vp]),
+    "o2m_conv2d_wgrad": (_i32, [C.POINTER(WgradDesc), _vp]),
+    "o2m_act_bwd_reduce": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "o2m_fold_scale_dot": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "o2m_instnorm_ws_floats": (C.c_size_t, [_i32, _i32, _i32]),
+    "o2m_instnorm_stats": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp]),
+    "o2m_instnorm_apply": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "o2m_instnorm_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "o2m_resample2d": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
+                              _i32, _vp]),
+    "o2m_pack_nchw": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "o2m_unpack_nhwc": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "o2m_reduce_blocks": (_i32, [_i64]),
+    "o2m_reduce_fwd": (_i32, [_vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp]),
+    "o2m_reduce_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp]),
+    "o2m_adam_step": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built "
+                "(run `python -m one_to_many_gan_amd.build` or __graft_entry__.build()). "
+                "There is no CPU or eager fallback."
+            )
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        if handle.o2m_abi_version() != ABI_VERSION:
+            raise RuntimeError("libo2m_hip.so ABI version mismatch: rebuild the extension")
+        _lib = handle
+    return _lib
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.bfloat16:
+        return BF16
+    if dt == torch.float32:
+        return F32
+    raise TypeError(f"unsupported activation dtype {dt}")
+
+
+def _stream(t: torch.Tensor):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def ptr(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("o2m HIP op called with a non-GPU tensor: the hot path has no CPU fallback")
+    if not t.is_contiguous():
+        raise RuntimeError("o2m HIP op needs contiguous tensors")
+    return C.c_void_p(t.data_ptr())
+
+
+def check(err: int, what: str):
+    if err != 0:
+        raise RuntimeError(f"{what} failed with code {err}")
+
+
+# ------------------------------------------------------------------------------- wrappers
+
+
+def conv2d_fwd(x, w, y, *, in_scale=None, out_scale=None, bias=None, residual=None, pad, pad_mode, act):
+    B, H, W, Ci = x.shape
+    Co, KH, KW, _ = w.shape
+    d = ConvDesc(ptr(x), ptr(w), ptr(y), ptr(in_scale), ptr(out_scale), ptr(bias), ptr(residual),
+                 B, H, W, Ci, Co, KH, KW, pad, pad_mode, act, dtype_code(x.dtype))
+    check(lib().o2m_conv2d_fwd(C.byref(d), _stream(x)), "o2m_conv2d_fwd")
+
+
+def conv2d_wgrad(x, gy, dw, *, in_scale=None, gy_scale=None, pad, pad_mode, splits=0):
+    B, H, W, Ci = x.shape
+    Co, KH, KW, _ = dw.shape
+    d = WgradDesc(ptr(x), ptr(gy), ptr(dw), ptr(in_scale), ptr(gy_scale), B, H, W, Ci, Co, KH, KW,
+                  pad, pad_mode, dtype_code(x.dtype), splits)
+    check(lib().o2m_conv2d_wgrad(C.byref(d), _stream(x)), "o2m_conv2d_wgrad")
+
+
+def act_bwd_reduce(g, y, residual, gu, sums, act):
+    B, P, Cn = g.shape[0], g.shape[1] * g.shape[2], g.shape[3]
+    check(lib().o2m_act_bwd_reduce(ptr(g), ptr(y), ptr(residual), ptr(gu), ptr(sums), B, P, Cn, act,
+                                   dtype_code(g.dtype), _stream(g)), "o2m_act_bwd_reduce")
+
+
+def fold_scale_dot(gpad, x, scale, gx, dots, pad):
+    B, H, W, Cn = gx.shape
+    check(lib().o2m_fold_scale_dot(ptr(gpad), ptr(x), ptr(scale), ptr(gx), ptr(dots), B, H, W, Cn, pad,
+                                   dtype_code(gx.dtype), _stream(gx)), "o2m_fold_scale_dot")
+
+
+def instnorm_ws_floats(B, P, Cn):
+    return int(lib().o2m_instnorm_ws_floats(B, P, Cn))
+
+
+def instnorm_stats(x, partial, mean_rstd, eps):
+    B, P, Cn = x.shape[0], x.shape[1] * x.shape[2], x.shape[3]
+    check(lib().o2m_instnorm_stats(ptr(x), ptr(partial), ptr(mean_rstd), B, P, Cn, eps,
+                                   dtype_code(x.dtype), _stream(x)), "o2m_instnorm_stats")
+
+
+def instnorm_apply(x, mean_rstd, residual, y, act):
+    B, P, Cn = x.shape[0], x.shape[1] * x.shape[2], x.shape[3]
+    check(lib().o2m_instnorm_apply(ptr(x), ptr(mean_rstd), ptr(residual), ptr(y), B, P, Cn, act,
+                                   dtype_code(x.dtype), _stream(x)), "o2m_instnorm_apply")
+
+
+def instnorm_bwd(g, x, mean_rstd, partial, gsums, gx, act):
+    B, P, Cn = x.shape[0], x.shape[1] * x.shape[2], x.shape[3]
+    check(lib().o2m_instnorm_bwd(ptr(g), ptr(x), ptr(mean_rstd), ptr(partial), ptr(gsums), ptr(gx), B, P,
+                                 Cn, act, dtype_code(x.dtype), _stream(x)), "o2m_instnorm_bwd")
+
+
+def resample2d(x, y, sy, wy, sx, wx, T):
+    B, H, W, Cn = x.shape
+    _, Ho, Wo, _ = y.shape
+    check(lib().o2m_resample2d(ptr(x), ptr(y), ptr(sy), ptr(wy), ptr(sx), ptr(wx), B, H, W, Ho, Wo, Cn,
+                               T, dtype_code(x.dtype), _stream(x)), "o2m_resample2d")
+
+
+def pack_nchw(src, dst):
+    B, Cn, H, W = src.shape
+    check(lib().o2m_pack_nchw(ptr(src), ptr(dst), B, Cn, H, W, dst.shape[3], dtype_code(dst.dtype),
+                              _stream(dst)), "o2m_pack_nchw")
+
+
+def unpack_nhwc(src, dst):
+    B, Cn, H, W = dst.shape
+    check(lib().o2m_unpack_nhwc(ptr(src), ptr(dst), B, Cn, H, W, src.shape[3], dtype_code(src.dtype),
+                                _stream(src)), "o2m_unpack_nhwc")
+
+
+def reduce_blocks(n):
+    return int(lib().o2m_reduce_blocks(n))
+
+
+def reduce_fwd(a, b, w, partials, mode):
+    B = a.shape[0]
+    nps = a.numel() // B
+    check(lib().o2m_reduce_fwd(ptr(a), ptr(b), ptr(w), ptr(partials), B, nps, mode, dtype_code(a.dtype),
+                               _stream(a)), "o2m_reduce_fwd")
+
+
+def reduce_bwd(a, b, w, coef, ga, mode):
+    B = a.shape[0]
+    nps = a.numel() // B
+    check(lib().o2m_reduce_bwd(ptr(a), ptr(b), ptr(w), ptr(coef), ptr(ga), B, nps, mode,
+                               dtype_code(a.dtype), _stream(a)), "o2m_reduce_bwd")
+
+
+def adam_step(p, g, m, v, step, lr, beta1, beta2, eps, grad_scale):
+    check(lib().o2m_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), ptr(step), p.numel(), lr, beta1, beta2,
+                              eps, grad_scale, _stream(p)), "o2m_adam_step")

@@ -1,0 +1,164 @@
+"""Step functions with the reference's signatures and return structure
+(src/core/training.py).  Differences that do not change results:
+
+* the generator forward of the discriminator step runs under ``no_grad`` (the reference
+  builds that graph and throws it away, training.py:98-99);
+* the discriminator's weight gradients are not computed in the generator step (the
+  reference computes them and zeroes them at the next discriminator step, training.py:88);
+* the logged scalars leave the device in ONE packed transfer per step function instead of
+  3 + 7 blocking ``.item()`` calls (training.py:13,125-128,250-257).
+"""
+
+from __future__ import annotations
+
+import contextlib
+import random
+from collections.abc import Iterator
+
+import torch
+import torch.nn.functional as F
+
+from .. import ops
+from ..model.loss import kl_loss_func, path_loss_func, style_cycle_loss_func
+
+
+class ImageBuffer:
+    """History pool of generated images (reference training.py:22-65).  Same Python
+    ``random`` draw sequence as the reference: one ``uniform`` per image once the pool is
+    full, plus one ``randint`` when the image is swapped."""
+
+    def __init__(self, buffer_size: int):
+        if buffer_size < 1:
+            raise ValueError
+        self.buffer_size = buffer_size
+        self.num_imgs = 0
+        self.images: list[torch.Tensor] = []
+
+    def __call__(self, images: torch.Tensor):
+        picked = []
+        for k in range(images.shape[0]):
+            fresh = images[k: k + 1].detach()
+            if self.num_imgs < self.buffer_size:
+                self.images.append(fresh)
+                self.num_imgs += 1
+                picked.append(fresh)
+                continue
+            if random.uniform(0, 1) > 0.5:
+                slot = random.randint(0, self.buffer_size - 1)
+                picked.append(self.images[slot].clone())
+                self.images[slot] = fresh
+            else:
+                picked.append(fresh)
+        return torch.cat(picked, 0)
+
+
+def _floats(*scalars):
+    """One device->host transfer for all logged scalars of a step."""
+    return torch.stack([s.detach().float().reshape(()) for s in scalars]).tolist()
+
+
+def _l1(a, b):
+    return ops.l1_sum(ops.to_internal(a), ops.to_internal(b)) / a.numel()
+
+
+def _mse_to(scores, target: float):
+    s = scores.float()
+    return F.mse_loss(s, torch.full_like(s, target))
+
+
+def _confidence(scores):
+    return torch.sign(scores.detach().float() * 2 - 1).mean()
+
+
+@contextlib.contextmanager
+def _frozen(module):
+    flags = [p.requires_grad for p in module.parameters()]
+    for p in module.parameters():
+        p.requires_grad_(False)
+    try:
+        yield
+    finally:
+        for p, f in zip(module.parameters(), flags):
+            p.requires_grad_(f)
+
+
+def discriminator_step(config, device, discriminator, generator, mapping_network,
+                       discriminator_optimiser, shoeprint_iter: Iterator[torch.Tensor],
+                       shoemark_iter: Iterator[torch.Tensor], image_buffer, ada, ada_p):
+    """One discriminator update; returns ``(loss, (real_confidence, fake_confidence))``
+    exactly like the reference (training.py:71-128)."""
+    batch = config["training"]["batch_size"]
+    discriminator_optimiser.zero_grad()
+
+    shoeprints = next(shoeprint_iter).to(device)
+    with torch.no_grad():
+        w = mapping_network.get_single_w(batch, generator.n_style_blocks, device, 1)
+        generated = generator(shoeprints, w)
+    fake = ada(image_buffer(generated))
+    real = ada(next(shoemark_iter).to(device))
+
+    fake_scores = discriminator(fake)
+    real_scores = discriminator(real)
+    loss = (_mse_to(real_scores, 1.0) + _mse_to(fake_scores, 0.0)) / 2
+
+    sign_real = _confidence(real_scores)
+    sign_fake = -_confidence(fake_scores)
+    ada_p.update_p(sign_real)
+
+    loss.backward()
+    discriminator_optimiser.step()
+    out = _floats(loss, sign_real, sign_fake)
+    return out[0], (out[1], out[2])
+
+
+def generator_step(config, device, generator, discriminator, mapping_network, style_extractor,
+                   generator_optimiser, mapping_network_optimiser, style_extractor_optimiser,
+                   shoeprint_iter: Iterator[torch.Tensor], shoemark_iter: Iterator[torch.Tensor], ada,
+                   *, kl_moment_hook=None):
+    """One generator / mapping-network / style-extractor update; returns
+    ``(total, (gan, rec, idt, kl, path, style))`` like the reference (training.py:136-257)."""
+    batch = config["training"]["batch_size"]
+    lam = config["optimisation"]
+    blocks = generator.n_style_blocks
+    for opt in (generator_optimiser, mapping_network_optimiser, style_extractor_optimiser):
+        opt.zero_grad()
+
+    shoeprints = next(shoeprint_iter).to(device)
+    shoemarks = next(shoemark_iter).to(device)
+
+    # both domains through the encoder in one 2B pass; KL on the joint latent
+    latents = generator.encode(torch.cat([shoeprints, shoemarks], dim=0))
+    kl = kl_loss_func(latents, moment_hook=kl_moment_hook)
+    if config["architecture"]["add_latent_noise"]:
+        latents = latents + torch.randn_like(latents)
+    z_print, z_mark = latents.chunk(2, dim=0)
+
+    w_zero = mapping_network.get_single_w(batch, blocks, device, 0)
+    rec = _l1(generator.decode(z_print, w_zero), shoeprints)
+
+    w_mark = style_extractor(shoemarks)
+    idt = _l1(generator.decode(z_mark, w_mark.expand(blocks, *w_mark.shape)), shoemarks)
+
+    w_trans = mapping_network.get_single_w(batch, blocks, device, 1)
+    generated = generator.decode(z_print, w_trans)
+    with _frozen(discriminator):
+        gan = _mse_to(discriminator(ada(generated)), 1.0)
+
+    style = style_cycle_loss_func(w_trans[-1], style_extractor(generated))
+
+    theta = torch.rand(batch).to(device)
+    lo, hi = lam["path_loss_jacobian_granularity"]
+    h = torch.ones_like(theta).uniform_(lo, hi)
+    d1, d2 = (theta + h / 2).clamp(0, 1), (theta - h / 2).clamp(0, 1)
+    w1, w2 = mapping_network.get_two_w(batch, blocks, device, (d1, d2))
+    path = path_loss_func(generator.extract(z_print, w1), generator.extract(z_print, w2), h)
+
+    total = (gan + lam["identity_loss_lambda"] * idt + lam["reconstruction_loss_lambda"] * rec
+             + lam["kl_loss_lambda"] * kl + lam["path_loss_lambda"] * path
+             + lam["style_cycle_loss_lambda"] * style)
+    total.backward()
+    generator_optimiser.step()
+    mapping_network_optimiser.step()
+    style_extractor_optimiser.step()
+    out = _floats(total, gan, rec, idt, kl, path, style)
+    return out[0], tuple(out[1:])

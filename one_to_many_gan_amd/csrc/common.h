@@ -1,0 +1,99 @@
+// Shared device helpers for libo2m_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/o2m_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;   // one MFMA 32x32x16 operand
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;  // one 32x32 accumulator tile
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define O2M_WAVE 64
+
+__device__ __forceinline__ unsigned short f2bf(float x) {
+  __bf16 h = (__bf16)x;  // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+  return __builtin_bit_cast(unsigned short, h);
+}
+__device__ __forceinline__ float bf2f(unsigned short b) {
+  return __builtin_bit_cast(float, (unsigned int)b << 16);
+}
+__device__ __forceinline__ unsigned int pack_bf2(float lo, float hi) {
+  return (unsigned int)f2bf(lo) | ((unsigned int)f2bf(hi) << 16);
+}
+
+// Element traits: storage type T is `unsigned short` (bf16 bits) or `float`.
+template <typename T> struct Elem;
+template <> struct Elem<unsigned short> {
+  static constexpr int dtype = O2M_BF16;
+  static __device__ __forceinline__ float ld(const unsigned short* p) { return bf2f(*p); }
+  static __device__ __forceinline__ void st(unsigned short* p, float v) { *p = f2bf(v); }
+};
+template <> struct Elem<float> {
+  static constexpr int dtype = O2M_F32;
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+
+// 8 consecutive channels <-> 8 floats (16 B of bf16 or 32 B of fp32; pointer 16-B aligned)
+__device__ __forceinline__ void load8(const unsigned short* p, float (&v)[8]) {
+  u32x4 r = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[2 * i] = __builtin_bit_cast(float, r[i] << 16);
+    v[2 * i + 1] = __builtin_bit_cast(float, r[i] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
+  f32x4 a = *reinterpret_cast<const f32x4*>(p);
+  f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
+}
+__device__ __forceinline__ void store8(unsigned short* p, const float (&v)[8]) {
+  u32x4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[i] = pack_bf2(v[2 * i], v[2 * i + 1]);
+  *reinterpret_cast<u32x4*>(p) = r;
+}
+__device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
+  f32x4 a, b;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { a[i] = v[i]; b[i] = v[4 + i]; }
+  *reinterpret_cast<f32x4*>(p) = a;
+  *reinterpret_cast<f32x4*>(p + 4) = b;
+}
+
+__device__ __forceinline__ float act_fwd(float v, int act) {
+  switch (act) {
+    case O2M_ACT_RELU: return v > 0.f ? v : 0.f;
+    case O2M_ACT_LRELU: return v > 0.f ? v : 0.2f * v;
+    case O2M_ACT_TANH: return tanhf(v);
+    default: return v;
+  }
+}
+// derivative expressed through the activation OUTPUT y
+__device__ __forceinline__ float act_bwd_from_out(float y, int act) {
+  switch (act) {
+    case O2M_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+    case O2M_ACT_LRELU: return y > 0.f ? 1.f : 0.2f;
+    case O2M_ACT_TANH: return 1.f - y * y;
+    default: return 1.f;
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+#define O2M_LAUNCH_CHECK()                        \
+  do {                                            \
+    hipError_t e__ = hipGetLastError();           \
+    if (e__ != hipSuccess) return (int)e__;       \
+  } while (0)

@@ -1,0 +1,586 @@
+// HBM-bound kernels of the training step (gfx950): every one streams NHWC tensors with 16-B
+// (bf16) / 32-B (fp32) per-lane accesses, lanes running over channel vectors so that a wave
+// touches whole contiguous pixel rows; per-(sample,channel) statistics are reduced
+// in registers over a pixel chunk, then across the block's pixel lanes through LDS.
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+// ---- geometry shared by the per-(b,c) reductions ----------------------------------------
+// A block covers one pixel chunk of one sample.  Thread t handles channel vector t % CV and
+// pixel lane t / CV (PL = NT / CV lanes); pixels are strided by PL inside the chunk.
+struct ChanGeom {
+  int CV, PL, chunk, nchunks;
+};
+__host__ __device__ inline ChanGeom chan_geom(int B, int P, int C) {
+  ChanGeom g;
+  g.CV = C / 8;
+  g.PL = g.CV >= NT ? 1 : NT / g.CV;
+  // aim for ~2048 blocks overall, at least 8 pixels per pixel lane
+  int want = (2048 + B - 1) / B;
+  int maxc = (P + g.PL * 8 - 1) / (g.PL * 8);
+  g.nchunks = want < maxc ? want : maxc;
+  if (g.nchunks < 1) g.nchunks = 1;
+  g.chunk = (P + g.nchunks - 1) / g.nchunks;
+  g.nchunks = (P + g.chunk - 1) / g.chunk;
+  return g;
+}
+
+// reduce NV values per thread across the block's pixel lanes; result valid on pl == 0
+template <int NV>
+__device__ __forceinline__ void lanes_reduce(float (&v)[NV], int cv, int pl, int CV, int PL,
+                                             float* sm) {
+  // sm: [PL][CV][NV]
+  if (cv < CV && pl < PL) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) sm[(pl * CV + cv) * NV + i] = v[i];
+  }
+  __syncthreads();
+  if (pl == 0 && cv < CV) {
+    for (int q = 1; q < PL; ++q)
+#pragma unroll
+      for (int i = 0; i < NV; ++i) v[i] += sm[(q * CV + cv) * NV + i];
+  }
+}
+
+// ---- act backward + per-(b,c) sums --------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(NT) void act_bwd_reduce_kernel(const T* g, const T* y, const T* res,
+                                                            T* gu, float* sums, int P, int C,
+                                                            int act, ChanGeom gm) {
+  extern __shared__ float sm[];
+  const int b = blockIdx.y, ch = blockIdx.x;
+  const int cv = threadIdx.x % gm.CV, pl = threadIdx.x / gm.CV;
+  const int pe = min(P, (ch + 1) * gm.chunk);
+  float acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  if (pl < gm.PL) {
+    for (int p = ch * gm.chunk + pl; p < pe; p += gm.PL) {
+      const size_t o = ((size_t)b * P + p) * C + cv * 8;
+      float gv[8], yv[8], rv[8], ov[8];
+      load8(g + o, gv);
+      load8(y + o, yv);
+      if (res) load8(res + o, rv);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float u = res ? yv[i] - rv[i] : yv[i];
+        float d = gv[i] * act_bwd_from_out(u, act);
+        ov[i] = d;
+        acc[i] += d;
+        acc[8 + i] += d * u;
+      }
+      store8(gu + o, ov);
+    }
+  }
+  lanes_reduce<16>(acc, cv, pl, gm.CV, gm.PL, sm);
+  if (pl == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float* s = sums + ((size_t)b * C + cv * 8 + i) * 2;
+      atomicAdd(s, acc[i]);
+      atomicAdd(s + 1, acc[8 + i]);
+    }
+  }
+}
+
+// ---- reflect-pad backward (fold) + style scale + style dot ----------------------------------
+template <typename T>
+__global__ __launch_bounds__(NT) void fold_scale_dot_kernel(const T* gpad, const T* x,
+                                                            const float* scale, T* gx,
+                                                            float* dots, int H, int W, int C,
+                                                            int pad, ChanGeom gm) {
+  extern __shared__ float sm[];
+  const int b = blockIdx.y, ch = blockIdx.x;
+  const int cv = threadIdx.x % gm.CV, pl = threadIdx.x / gm.CV;
+  const int P = H * W, Hp = H + 2 * pad, Wp = W + 2 * pad;
+  const int pe = min(P, (ch + 1) * gm.chunk);
+  float acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  float sc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) sc[i] = scale ? scale[(size_t)b * C + cv * 8 + i] : 1.f;
+  if (pl < gm.PL) {
+    for (int p = ch * gm.chunk + pl; p < pe; p += gm.PL) {
+      const int yy = p / W, xx = p - yy * W;
+      int ys[3], xs[3], ny = 0, nx = 0;
+      ys[ny++] = yy + pad;
+      if (yy >= 1 && yy <= pad) ys[ny++] = pad - yy;
+      if (yy >= H - 1 - pad && yy <= H - 2) ys[ny++] = 2 * H - 2 + pad - yy;
+      xs[nx++] = xx + pad;
+      if (xx >= 1 && xx <= pad) xs[nx++] = pad - xx;
+      if (xx >= W - 1 - pad && xx <= W - 2) xs[nx++] = 2 * W - 2 + pad - xx;
+      float f[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) f[i] = 0.f;
+      for (int a = 0; a < ny; ++a)
+        for (int c = 0; c < nx; ++c) {
+          float t[8];
+          load8(gpad + (((size_t)b * Hp + ys[a]) * Wp + xs[c]) * C + cv * 8, t);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) f[i] += t[i];
+        }
+      const size_t o = ((size_t)b * P + p) * C + cv * 8;
+      if (dots) {
+        float xv[8];
+        load8(x + o, xv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] += f[i] * xv[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) f[i] *= sc[i];
+      store8(gx + o, f);
+    }
+  }
+  if (dots) {
+    lanes_reduce<8>(acc, cv, pl, gm.CV, gm.PL, sm);
+    if (pl == 0)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) atomicAdd(dots + (size_t)b * C + cv * 8 + i, acc[i]);
+  }
+}
+
+// ---- instance norm ---------------------------------------------------------------------------
+// MODE 0: {sum x, sum x^2};  MODE 1 (backward): {sum gh, sum gh*xh}
+template <typename T, int MODE>
+__global__ __launch_bounds__(NT) void in_partial_kernel(const T* x, const T* g,
+                                                        const float* mean_rstd, float* partial,
+                                                        int P, int C, int act, ChanGeom gm) {
+  extern __shared__ float sm[];
+  const int b = blockIdx.y, ch = blockIdx.x;
+  const int cv = threadIdx.x % gm.CV, pl = threadIdx.x / gm.CV;
+  const int pe = min(P, (ch + 1) * gm.chunk);
+  float acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  float mu[8], rs[8];
+  if (MODE == 1) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      mu[i] = mean_rstd[((size_t)b * C + cv * 8 + i) * 2];
+      rs[i] = mean_rstd[((size_t)b * C + cv * 8 + i) * 2 + 1];
+    }
+  }
+  if (pl < gm.PL) {
+    for (int p = ch * gm.chunk + pl; p < pe; p += gm.PL) {
+      const size_t o = ((size_t)b * P + p) * C + cv * 8;
+      float xv[8];
+      load8(x + o, xv);
+      if (MODE == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { acc[i] += xv[i]; acc[8 + i] += xv[i] * xv[i]; }
+      } else {
+        float gv[8];
+        load8(g + o, gv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          float xh = (xv[i] - mu[i]) * rs[i];
+          float gh = gv[i] * act_bwd_from_out(xh, act);  // relu/lrelu: sign(xh) == sign(out)
+          acc[i] += gh;
+          acc[8 + i] += gh * xh;
+        }
+      }
+    }
+  }
+  lanes_reduce<16>(acc, cv, pl, gm.CV, gm.PL, sm);
+  if (pl == 0) {
+    float* dst = partial + (((size_t)b * gm.nchunks + ch) * C + cv * 8) * 2;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { dst[2 * i] = acc[i]; dst[2 * i + 1] = acc[8 + i]; }
+  }
+}
+
+// MODE 0: -> {mean, rstd};  MODE 1: -> {mean gh, mean gh*xh}
+template <int MODE>
+__global__ void in_finalize_kernel(const float* partial, float* out, int B, int P, int C,
+                                   int nchunks, float eps) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * C) return;
+  const int b = idx / C, c = idx - b * C;
+  float s0 = 0.f, s1 = 0.f;
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const float* p = partial + (((size_t)b * nchunks + ch) * C + c) * 2;
+    s0 += p[0];
+    s1 += p[1];
+  }
+  const float inv = 1.f / (float)P;
+  if (MODE == 0) {
+    float mean = s0 * inv;
+    float var = fmaxf(s1 * inv - mean * mean, 0.f);
+    out[(size_t)idx * 2] = mean;
+    out[(size_t)idx * 2 + 1] = rsqrtf(var + eps);
+  } else {
+    out[(size_t)idx * 2] = s0 * inv;
+    out[(size_t)idx * 2 + 1] = s1 * inv;
+  }
+}
+
+// MODE 0: y = act((x-mean)*rstd) + res ;  MODE 1: gx = rstd*(gh - m1 - xh*m2)
+template <typename T, int MODE>
+__global__ __launch_bounds__(NT) void in_apply_kernel(const T* x, const T* g,
+                                                      const float* mean_rstd, const float* gsums,
+                                                      const T* res, T* out, int P, int C, int act,
+                                                      long nvec) {
+  const int CV = C / 8;
+  for (long v = (long)blockIdx.x * NT + threadIdx.x; v < nvec; v += (long)gridDim.x * NT) {
+    const int cv = (int)(v % CV);
+    const long bp = v / CV;
+    const int b = (int)(bp / P);
+    const size_t o = (size_t)v * 8;
+    const float* mr = mean_rstd + ((size_t)b * C + cv * 8) * 2;
+    float xv[8], ov[8];
+    load8(x + o, xv);
+    if (MODE == 0) {
+      float rv[8];
+      if (res) load8(res + o, rv);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float t = act_fwd((xv[i] - mr[2 * i]) * mr[2 * i + 1], act);
+        ov[i] = res ? t + rv[i] : t;
+      }
+    } else {
+      float gv[8];
+      load8(g + o, gv);
+      const float* gs = gsums + ((size_t)b * C + cv * 8) * 2;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float xh = (xv[i] - mr[2 * i]) * mr[2 * i + 1];
+        float gh = gv[i] * act_bwd_from_out(xh, act);
+        ov[i] = mr[2 * i + 1] * (gh - gs[2 * i] - xh * gs[2 * i + 1]);
+      }
+    }
+    store8(out + o, ov);
+  }
+}
+
+// ---- separable banded resample -----------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(NT) void resample_kernel(const T* x, T* y, const int* sy,
+                                                      const float* wy, const int* sx,
+                                                      const float* wx, int H, int W, int Ho,
+                                                      int Wo, int C, int Tn, long nvec) {
+  const int CV = C / 8;
+  for (long v = (long)blockIdx.x * NT + threadIdx.x; v < nvec; v += (long)gridDim.x * NT) {
+    const int cv = (int)(v % CV);
+    long r = v / CV;
+    const int ox = (int)(r % Wo); r /= Wo;
+    const int oy = (int)(r % Ho);
+    const int b = (int)(r / Ho);
+    const int y0 = sy[oy], x0 = sx[ox];
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    for (int ty = 0; ty < Tn; ++ty) {
+      const float a = wy[oy * Tn + ty];
+      const int iy = y0 + ty;
+      if (a == 0.f || iy >= H) continue;
+      for (int tx = 0; tx < Tn; ++tx) {
+        const float wgt = a * wx[ox * Tn + tx];
+        const int ix = x0 + tx;
+        if (wgt == 0.f || ix >= W) continue;
+        float t[8];
+        load8(x + (((size_t)b * H + iy) * W + ix) * C + cv * 8, t);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] += wgt * t[i];
+      }
+    }
+    store8(y + (size_t)v * 8, acc);
+  }
+}
+
+// ---- NCHW fp32 <-> NHWC (channel padded) ----------------------------------------------------
+template <typename T>
+__global__ void pack_kernel(const float* src, T* dst, int C, int HW, int Cp, long npix) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix;
+       i += (long)gridDim.x * blockDim.x) {
+    const long b = i / HW, p = i - b * HW;
+    for (int c0 = 0; c0 < Cp; c0 += 8) {
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = (c0 + k) < C ? src[((size_t)b * C + c0 + k) * HW + p] : 0.f;
+      store8(dst + (size_t)i * Cp + c0, v);
+    }
+  }
+}
+template <typename T>
+__global__ void unpack_kernel(const T* src, float* dst, int C, int HW, int Cp, long npix) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix;
+       i += (long)gridDim.x * blockDim.x) {
+    const long b = i / HW, p = i - b * HW;
+    for (int c0 = 0; c0 < C; c0 += 8) {
+      float v[8];
+      load8(src + (size_t)i * Cp + c0, v);
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (c0 + k < C) dst[((size_t)b * C + c0 + k) * HW + p] = v[k];
+    }
+  }
+}
+
+// ---- loss reductions -------------------------------------------------------------------------
+constexpr int RED_VEC_PER_BLOCK = NT * 8;  // 8 vectors (64 elements) per thread
+
+template <typename T>
+__global__ __launch_bounds__(NT) void reduce_fwd_kernel(const T* a, const T* b, const float* w,
+                                                        float* partials, long nps_vec, long nvec,
+                                                        int mode, int nblocks) {
+  __shared__ float sm[2][NT / 64];
+  float s0 = 0.f, s1 = 0.f;
+  const long base = (long)blockIdx.x * RED_VEC_PER_BLOCK;
+  for (int it = 0; it < 8; ++it) {
+    const long v = base + it * NT + threadIdx.x;
+    if (v >= nvec) break;
+    float av[8], bv[8];
+    load8(a + (size_t)v * 8, av);
+    if (b) load8(b + (size_t)v * 8, bv);
+    const float ws = (w && mode == O2M_RED_SQ) ? w[v / nps_vec] : 1.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float dlt = b ? av[i] - bv[i] : av[i];
+      if (mode == O2M_RED_L1) s0 += fabsf(dlt);
+      else if (mode == O2M_RED_SQ) s0 += ws * dlt * dlt;
+      else { s0 += av[i]; s1 += av[i] * av[i]; }
+    }
+  }
+  s0 = wave_sum(s0);
+  s1 = wave_sum(s1);
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sm[0][wv] = s0; sm[1][wv] = s1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t0 = 0.f, t1 = 0.f;
+    for (int i = 0; i < NT / 64; ++i) { t0 += sm[0][i]; t1 += sm[1][i]; }
+    partials[blockIdx.x] = t0;
+    if (mode == O2M_RED_MOM) partials[nblocks + blockIdx.x] = t1;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void reduce_bwd_kernel(const T* a, const T* b, const float* w,
+                                                        const float* coef, T* ga, long nps_vec,
+                                                        long nvec, int mode) {
+  const float c0 = coef[0];
+  const float c1 = mode == O2M_RED_MOM ? coef[1] : 0.f;
+  for (long v = (long)blockIdx.x * NT + threadIdx.x; v < nvec; v += (long)gridDim.x * NT) {
+    float av[8], bv[8], ov[8];
+    load8(a + (size_t)v * 8, av);
+    if (b) load8(b + (size_t)v * 8, bv);
+    const float ws = (w && mode == O2M_RED_SQ) ? w[v / nps_vec] : 1.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float dlt = b ? av[i] - bv[i] : av[i];
+      if (mode == O2M_RED_L1) ov[i] = dlt > 0.f ? c0 : (dlt < 0.f ? -c0 : 0.f);
+      else if (mode == O2M_RED_SQ) ov[i] = c0 * ws * dlt;
+      else ov[i] = c0 + c1 * av[i];
+    }
+    store8(ga + (size_t)v * 8, ov);
+  }
+}
+
+// ---- fused Adam ------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void adam_kernel(float* p, const float* g, float* m, float* v,
+                                                  const float* step, long n, float lr, float b1,
+                                                  float b2, float eps, float gscale) {
+  const float t = step[0];
+  const float bc1 = 1.f - powf(b1, t);
+  const float bc2_sqrt = sqrtf(1.f - powf(b2, t));
+  const float step_size = lr / bc1;
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+    const float gi = g[i] * gscale;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+  }
+}
+
+inline unsigned grid_for(long n, int per_block = NT) {
+  long g = (n + per_block - 1) / per_block;
+  if (g > 8192) g = 8192;  // grid-stride the rest
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+#define DISPATCH_T(dtype, ...)                                             \
+  if ((dtype) == O2M_BF16) { using T = unsigned short; __VA_ARGS__; }      \
+  else if ((dtype) == O2M_F32) { using T = float; __VA_ARGS__; }           \
+  else return O2M_ERR_BAD_ARG;
+
+}  // namespace
+
+extern "C" {
+
+int o2m_abi_version(void) { return 1; }
+
+int o2m_act_bwd_reduce(const void* g, const void* y, const void* residual, void* gu, float* sums,
+                       int32_t B, int32_t P, int32_t C, int32_t act, int32_t dtype, void* stream) {
+  if (!g || !y || !gu || !sums || B <= 0 || P <= 0 || C <= 0 || (C & 7) || C > 8 * NT)
+    return O2M_ERR_BAD_ARG;
+  ChanGeom gm = chan_geom(B, P, C);
+  const size_t lds = (size_t)gm.PL * gm.CV * 16 * sizeof(float);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(act_bwd_reduce_kernel<T>, dim3(gm.nchunks, B), dim3(NT), lds, s,
+                                       (const T*)g, (const T*)y, (const T*)residual, (T*)gu, sums, P,
+                                       C, act, gm));
+  O2M_LAUNCH_CHECK();
+  return 0;
+}
+
+int o2m_fold_scale_dot(const void* gpad, const void* x, const float* scale, void* gx, float* dots,
+                       int32_t B, int32_t H, int32_t W, int32_t C, int32_t pad, int32_t dtype,
+                       void* stream) {
+  if (!gpad || !gx || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7) || C > 8 * NT || pad < 0)
+    return O2M_ERR_BAD_ARG;
+  if (pad >= H || pad >= W || (dots && !x)) return O2M_ERR_BAD_ARG;
+  ChanGeom gm = chan_geom(B, H * W, C);
+  const size_t lds = (size_t)gm.PL * gm.CV * 8 * sizeof(float);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(fold_scale_dot_kernel<T>, dim3(gm.nchunks, B), dim3(NT), lds, s,
+                                       (const T*)gpad, (const T*)x, scale, (T*)gx, dots, H, W, C, pad,
+                                       gm));
+  O2M_LAUNCH_CHECK();
+  return 0;
+}
+
+size_t o2m_instnorm_ws_floats(int32_t B, int32_t P, int32_t C) {
+  if (B <= 0 || P <= 0 || C <= 0 || (C & 7)) return 0;
+  ChanGeom gm = chan_geom(B, P, C);
+  return (size_t)B * gm.nchunks * C * 2;
+}
+
+int o2m_instnorm_stats(const void* x, float* partial, float* mean_rstd, int32_t B, int32_t P,
+                       int32_t C, float eps, int32_t dtype, void* stream) {
+  if (!x || !partial || !mean_rstd || B <= 0 || P <= 0 || C <= 0 || (C & 7) || C > 8 * NT)
+    return O2M_ERR_BAD_ARG;
+  ChanGeom gm = chan_geom(B, P, C);
+  const size_t lds = (size_t)gm.PL * gm.CV * 16 * sizeof(float);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((in_partial_kernel<T, 0>), dim3(gm.nchunks, B), dim3(NT), lds, s,
+                                       (const T*)x, (const T*)nullptr, (const float*)nullptr, partial,
+                                       P, C, 0, gm));
+  O2M_LAUNCH_CHECK();
+  hipLaunchKernelGGL(in_finalize_kernel<0>, dim3((B * C + 255) / 256), dim3(256), 0, s, partial,
+                     mean_rstd, B, P, C, gm.nchunks, eps);
+  O2M_LAUNCH_CHECK();
+  return 0;
+}
+
+int o2m_instnorm_apply(const void* x, const float* mean_rstd, const void* residual, void* y,
+                       int32_t B, int32_t P, int32_t C, int32_t act, int32_t dtype, void* stream) {
+  if (!x || !mean_rstd || !y || B <= 0 || P <= 0 || C <= 0 || (C & 7)) return O2M_ERR_BAD_ARG;
+  const long nvec = (long)B * P * (C / 8);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((in_apply_kernel<T, 0>), dim3(grid_for(nvec)), dim3(NT), 0, s,
+                                       (const T*)x, (const T*)nullptr, mean_rstd,
+                                       (const float*)nullptr, (const T*)residual, (T*)y, P, C, act,
+                                       nvec));
+  O2M_LAUNCH_CHECK();
+  return 0;
+}
+
+int o2m_instnorm_bwd(const void* g, const void* x, const float* mean_rstd, float* partial,
+                     float* gsums, void* gx, int32_t B, int32_t P, int32_t C, int32_t act,
+                     int32_t dtype, void* stream) {
+  if (!g || !x || !mean_rstd || !partial || !gsums || !gx) return O2M_ERR_BAD_ARG;
+  if (B <= 0 || P <= 0 || C <= 0 || (C & 7) || C > 8 * NT || act == O2M_ACT_TANH)
+    return O2M_ERR_BAD_ARG;
+  ChanGeom gm = chan_geom(B, P, C);
+  const size_t lds = (size_t)gm.PL * gm.CV * 16 * sizeof(float);
+  const long nvec = (long)B * P * (C / 8);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  DISPATCH_T(dtype, {
+    hipLaunchKernelGGL((in_partial_kernel<T, 1>), dim3(gm.nchunks, B), dim3(NT), lds, s, (const T*)x,
+                       (const T*)g, mean_rstd, partial, P, C, act, gm);
+    hipLaunchKernelGGL(in_finalize_kernel<1>, dim3((B * C + 255) / 256), dim3(256), 0, s, partial,
+                       gsums, B, P, C, gm.nchunks, 0.f);
+    hipLaunchKernelGGL((in_apply_kernel<T, 1>), dim3(grid_for(nvec)), dim3(NT), 0, s, (const T*)x,
+                       (const T*)g, mean_rstd, gsums, (const T*)nullptr, (T*)gx, P, C, act, nvec);
+  });
+  O2M_LAUNCH_CHECK();
+  return 0;
+}
+
+int o2m_resample2d(const void* x, void* y, const int32_t* sy, const float* wy, const int32_t* sx,
+                   const float* wx, int32_t B, int32_t H, int32_t W, int32_t Ho, int32_t Wo,
+                   int32_t C, int32_t T_, int32_t dtype, void* stream) {
+  if (!x || !y || !sy || !wy || !sx || !wx) return O2M_ERR_BAD_ARG;
+  if (B <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || (C & 7) || T_ <= 0)
+    return O2M_ERR_BAD_ARG;
+  const long nvec = (long)B * Ho * Wo * (C / 8);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(resample_kernel<T>, dim3(grid_for(nvec)), dim3(NT), 0, s,
+                                       (const T*)x, (T*)y, sy, wy, sx, wx, H, W, Ho, Wo, C, T_, nvec));
+  O2M_LAUNCH_CHECK();
+  return 0;
+}
+
+int o2m_pack_nchw(const float* src, void* dst, int32_t B, int32_t C, int32_t H, int32_t W,
+                  int32_t Cp, int32_t dtype, void* stream) {
+  if (!src || !dst || B <= 0 || C <= 0 || H <= 0 || W <= 0 || Cp < C || (Cp & 7)) return O2M_ERR_BAD_ARG;
+  const long npix = (long)B * H * W;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(pack_kernel<T>, dim3(grid_for(npix)), dim3(NT), 0, s, src,
+                                       (T*)dst, C, H * W, Cp, npix));
+  O2M_LAUNCH_CHECK();
+  return 0;
+}
+
+int o2m_unpack_nhwc(const void* src, float* dst, int32_t B, int32_t C, int32_t H, int32_t W,
+                    int32_t Cp, int32_t dtype, void* stream) {
+  if (!src || !dst || B <= 0 || C <= 0 || H <= 0 || W <= 0 || Cp < C || (Cp & 7)) return O2M_ERR_BAD_ARG;
+  const long npix = (long)B * H * W;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(unpack_kernel<T>, dim3(grid_for(npix)), dim3(NT), 0, s,
+                                       (const T*)src, dst, C, H * W, Cp, npix));
+  O2M_LAUNCH_CHECK();
+  return 0;
+}
+
+int32_t o2m_reduce_blocks(int64_t n) {
+  if (n <= 0 || (n & 7)) return 0;
+  const long nvec = n / 8;
+  return (int32_t)((nvec + RED_VEC_PER_BLOCK - 1) / RED_VEC_PER_BLOCK);
+}
+
+int o2m_reduce_fwd(const void* a, const void* b, const float* w, float* partials, int32_t B,
+                   int64_t n_per_sample, int32_t mode, int32_t dtype, void* stream) {
+  if (!a || !partials || B <= 0 || n_per_sample <= 0 || (n_per_sample & 7)) return O2M_ERR_BAD_ARG;
+  if (mode < O2M_RED_L1 || mode > O2M_RED_MOM) return O2M_ERR_BAD_ARG;
+  const long nvec = (long)B * n_per_sample / 8;
+  const int nblocks = o2m_reduce_blocks((int64_t)B * n_per_sample);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(reduce_fwd_kernel<T>, dim3(nblocks), dim3(NT), 0, s, (const T*)a,
+                                       (const T*)b, w, partials, (long)(n_per_sample / 8), nvec, mode,
+                                       nblocks));
+  O2M_LAUNCH_CHECK();
+  return 0;
+}
+
+int o2m_reduce_bwd(const void* a, const void* b, const float* w, const float* coef, void* ga,
+                   int32_t B, int64_t n_per_sample, int32_t mode, int32_t dtype, void* stream) {
+  if (!a || !coef || !ga || B <= 0 || n_per_sample <= 0 || (n_per_sample & 7)) return O2M_ERR_BAD_ARG;
+  if (mode < O2M_RED_L1 || mode > O2M_RED_MOM) return O2M_ERR_BAD_ARG;
+  const long nvec = (long)B * n_per_sample / 8;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(reduce_bwd_kernel<T>, dim3(grid_for(nvec)), dim3(NT), 0, s,
+                                       (const T*)a, (const T*)b, w, coef, (T*)ga,
+                                       (long)(n_per_sample / 8), nvec, mode));
+  O2M_LAUNCH_CHECK();
+  return 0;
+}
+
+int o2m_adam_step(float* p, const float* g, float* m, float* v, const float* step, int64_t n,
+                  float lr, float beta1, float beta2, float eps, float grad_scale, void* stream) {
+  if (!p || !g || !m || !v || !step || n <= 0) return O2M_ERR_BAD_ARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(NT), 0, s, p, g, m, v, step, (long)n, lr,
+                     beta1, beta2, eps, grad_scale);
+  O2M_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,77 @@
+"""Residual blocks with the reference's names and state_dict keys (src/model/blocks.py).
+
+The ``conv_block`` containers keep the reference's slot layout (so ``conv_block.1`` /
+``conv_block.5`` / ``conv_block.4`` carry the parameters), but the block is executed as a
+fixed fused plan: reflection pads live in the conv loaders, ReLU and the residual add in
+the conv / norm epilogues.
+"""
+
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from .. import _hip as H
+from .. import ops
+from .layers import Conv2dWeightModulate, EqualisedConv2d
+
+
+class _Slot(nn.Module):
+    """Parameter-free position in a reference ``Sequential`` (pad / norm / activation); the
+    work it stands for is fused into the neighbouring kernel."""
+
+    def __init__(self, what: str):
+        super().__init__()
+        self.what = what
+
+    def extra_repr(self):
+        return f"fused: {self.what}"
+
+
+class ResnetBlock(nn.Module):
+    """x + IN(conv(rpad(ReLU(IN(conv(rpad(x))))))) (reference blocks.py:9-33)."""
+
+    def __init__(self, dim: int, *, use_bias: bool = False):
+        super().__init__()
+        self.dim = dim
+        self.conv_block = nn.Sequential(
+            _Slot("ReflectionPad2d(1) -> conv loader"),
+            EqualisedConv2d(dim, dim, kernel_size=3, padding=0, use_bias=use_bias),
+            _Slot("InstanceNorm2d -> instnorm kernels"),
+            _Slot("ReLU -> instnorm apply"),
+            _Slot("ReflectionPad2d(1) -> conv loader"),
+            EqualisedConv2d(dim, dim, kernel_size=3, padding=0, use_bias=use_bias),
+            _Slot("InstanceNorm2d (+ residual add) -> instnorm kernels"),
+        )
+
+    def run(self, t):
+        u = self.conv_block[1].run(t, reflect=1)
+        u = ops.instance_norm_act(u, H.ACT_RELU)
+        u = self.conv_block[5].run(u, reflect=1)
+        return ops.instance_norm_act(u, H.ACT_NONE, residual=t)
+
+    def forward(self, x: torch.Tensor):
+        return ops.to_public(self.run(ops.to_internal(x)), self.dim)
+
+
+class ModulatedResnetBlock(nn.Module):
+    """x + modconv(rpad(ReLU(modconv(rpad(x), w))), w) (reference blocks.py:36-68); both
+    convs get the same ``w`` but own their ``to_style``."""
+
+    def __init__(self, dim: int, w_dim: int, *, use_bias: bool = False):
+        super().__init__()
+        self.dim = dim
+        self.conv_block = nn.ModuleList([
+            _Slot("ReflectionPad2d(1) -> conv loader"),
+            Conv2dWeightModulate(dim, dim, w_dim=w_dim, kernel_size=3, padding=0, use_bias=use_bias),
+            _Slot("ReLU -> conv epilogue"),
+            _Slot("ReflectionPad2d(1) -> conv loader"),
+            Conv2dWeightModulate(dim, dim, w_dim=w_dim, kernel_size=3, padding=0, use_bias=use_bias),
+        ])
+
+    def run(self, t, w):
+        u = self.conv_block[1].run(t, w, reflect=1, act=H.ACT_RELU)
+        return self.conv_block[4].run(u, w, reflect=1, residual=t)
+
+    def forward(self, x: torch.Tensor, w: torch.Tensor):
+        return ops.to_public(self.run(ops.to_internal(x), w), self.dim)

@@ -1,0 +1,198 @@
+"""The four networks with the reference's public API and state_dict keys
+(src/model/builder.py), executed as fused plans over the HIP kernels.
+
+Public tensors are logical NCHW; inside a network everything flows as NHWC buffers in the
+compute dtype (ops.py).  ``encoder`` / ``decoder`` / ``model`` containers reproduce the
+reference's slot indices, so checkpoints of either code base load into the other.
+"""
+
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .. import _hip as H
+from .. import ops
+from .blocks import ModulatedResnetBlock, ResnetBlock, _Slot
+from .layers import Conv2dWeightModulate, DownSample, EqualisedConv2d, EqualisedLinear, UpSample
+
+
+class MappingNetwork(nn.Module):
+    """z -> w MLP plus the style sampling helpers (reference builder.py:16-132).
+
+    B x w_dim work: plain torch.  The CPU-RNG draw order of the reference is part of the
+    contract (mix decision, crossover, z1, z2) and is kept exactly.
+    """
+
+    def __init__(self, features: int, n_layers: int, style_mixing_prob: float):
+        super().__init__()
+        self.d_latent = features
+        self.style_mixing_prob = style_mixing_prob
+        stack = []
+        for i in range(n_layers):
+            stack.append(EqualisedLinear(features, features))
+            last = i == n_layers - 1
+            # the final ReLU makes theta = 0 map to the zero style (reference builder.py:35-36)
+            stack.append(nn.ReLU(inplace=True) if last else nn.LeakyReLU(0.2, inplace=True))
+        self.net = nn.Sequential(*stack)
+        self.register_buffer("shoeprint_style_vector", torch.zeros(1, 1, features), persistent=False)
+
+    def forward(self, z: torch.Tensor):
+        return self.net(F.normalize(z.float(), dim=1))
+
+    def _sample(self, batch_size, device):
+        return self.forward(torch.randn(batch_size, self.d_latent).to(device))
+
+    def _get_style_vector(self, batch_size, n_gen_blocks, device, *, mix_styles=True):
+        if mix_styles and torch.rand(()).lt(self.style_mixing_prob):
+            cut = int(torch.randint(0, n_gen_blocks, ()))
+            first, second = self._sample(batch_size, device), self._sample(batch_size, device)
+            return torch.cat((first.expand(cut, -1, -1), second.expand(n_gen_blocks - cut, -1, -1)), 0)
+        return self._sample(batch_size, device).expand(n_gen_blocks, -1, -1)
+
+    def get_single_w(self, batch_size, n_gen_blocks, device, domain_variable, *, mix_styles=True):
+        base = self.shoeprint_style_vector
+        if domain_variable == 0:  # no RNG draw on this path (reference builder.py:87-90)
+            return base.expand(n_gen_blocks, batch_size, self.d_latent)
+        style = self._get_style_vector(batch_size, n_gen_blocks, device, mix_styles=mix_styles)
+        if isinstance(domain_variable, torch.Tensor):
+            theta = domain_variable.view(1, -1, 1)
+        else:
+            theta = torch.full((1, 1, 1), float(domain_variable), device=device)
+        return torch.lerp(base, style, theta)
+
+    def get_two_w(self, batch_size, n_gen_blocks, device, domain_variables, *, mix_styles=True):
+        style = self._get_style_vector(batch_size, n_gen_blocks, device, mix_styles=mix_styles)
+        base = self.shoeprint_style_vector
+        return tuple(torch.lerp(base, style, d.view(1, -1, 1)) for d in domain_variables)
+
+
+class Generator(nn.Module):
+    """Encoder (InstanceNorm ResNet) + weight-modulated decoder (reference builder.py:138-253)."""
+
+    def __init__(self, input_nc: int, w_dim: int, image_size, min_latent_resolution: int,
+                 n_resnet_blocks: int, start_filters: int = 64):
+        super().__init__()
+        self.input_nc = input_nc
+        f = start_filters
+        n_down = math.ceil(math.log2(min(image_size) / min_latent_resolution))
+        enc = [_Slot("ReflectionPad2d(3) -> conv loader"), EqualisedConv2d(input_nc, f, kernel_size=7),
+               _Slot("InstanceNorm2d"), _Slot("ReLU")]
+        for _ in range(n_down):
+            enc += [EqualisedConv2d(f, 2 * f, kernel_size=3, padding=1), _Slot("InstanceNorm2d"),
+                    _Slot("ReLU"), DownSample()]
+            f *= 2
+        enc += [ResnetBlock(f) for _ in range(n_resnet_blocks // 2)]
+        self.encoder = nn.Sequential(*enc)
+        self.latent_nc = f
+
+        dec = [ModulatedResnetBlock(f, w_dim=w_dim) for _ in range(math.ceil(n_resnet_blocks / 2))]
+        for _ in range(n_down):
+            dec += [UpSample(), Conv2dWeightModulate(f, f // 2, kernel_size=3, padding=1, w_dim=w_dim),
+                    _Slot("ReLU -> conv epilogue")]
+            f //= 2
+        dec += [_Slot("ReflectionPad2d(3) -> conv loader"), EqualisedConv2d(f, input_nc, kernel_size=7),
+                _Slot("Tanh -> conv epilogue")]
+        self.decoder = nn.ModuleList(dec)
+        self.n_style_blocks = sum(
+            [isinstance(m, (ModulatedResnetBlock, Conv2dWeightModulate)) for m in self.decoder])
+
+    # ---- fused plans on internal buffers -------------------------------------------------
+    def _encode(self, t):
+        mods = list(self.encoder)
+        t = ops.instance_norm_act(mods[1].run(t, reflect=3), H.ACT_RELU)
+        for m in mods[4:]:
+            if isinstance(m, EqualisedConv2d):
+                t = ops.instance_norm_act(m.run(t), H.ACT_RELU)
+            elif isinstance(m, (DownSample, ResnetBlock)):
+                t = m.run(t)
+        return t
+
+    def _decode(self, t, w, collect: bool):
+        feats, i = [], 0
+        for m in self.decoder:
+            if isinstance(m, ModulatedResnetBlock):
+                t = m.run(t, w[i])
+            elif isinstance(m, Conv2dWeightModulate):
+                # extract() returns its last map BEFORE the ReLU; the earlier ones come back
+                # post-ReLU because the reference's in-place ReLU aliases them (builder.py:196,241)
+                last = collect and i + 1 == self.n_style_blocks
+                t = m.run(t, w[i], act=H.ACT_NONE if last else H.ACT_RELU)
+            elif isinstance(m, UpSample):
+                t = m.run(t)
+                continue
+            elif isinstance(m, EqualisedConv2d):
+                if collect:
+                    break
+                return ops.to_public(m.run(t, reflect=3, act=H.ACT_TANH), self.input_nc)
+            else:
+                continue
+            i += 1
+            if collect:
+                feats.append(ops.to_public(t, m.out_features if isinstance(m, Conv2dWeightModulate) else m.dim))
+                if i == self.n_style_blocks:
+                    return feats
+        raise ValueError("No return layers specified.")
+
+    # ---- reference API -----------------------------------------------------------------------
+    def encode(self, x: torch.Tensor):
+        """Encode x to latent space z."""
+        return ops.to_public(self._encode(ops.to_internal(x)), self.latent_nc)
+
+    def decode(self, z: torch.Tensor, w: torch.Tensor):
+        """Decode from latent space z to image, using style vector w."""
+        return self._decode(ops.to_internal(z), w, collect=False)
+
+    def extract(self, z: torch.Tensor, w: torch.Tensor):
+        """Return the feature map behind every style block."""
+        return self._decode(ops.to_internal(z), w, collect=True)
+
+    def forward(self, x: torch.Tensor, w: torch.Tensor):
+        return self._decode(self._encode(ops.to_internal(x)), w, collect=False)
+
+
+def _patch_trunk(input_nc: int):
+    return [
+        EqualisedConv2d(input_nc, 64, kernel_size=4, padding=1), _Slot("LeakyReLU(0.2) -> conv epilogue"),
+        DownSample(),
+        EqualisedConv2d(64, 128, kernel_size=4, padding=1), _Slot("InstanceNorm2d"), _Slot("LeakyReLU(0.2)"),
+        DownSample(),
+        EqualisedConv2d(128, 256, kernel_size=4, padding=1), _Slot("InstanceNorm2d"), _Slot("LeakyReLU(0.2)"),
+        DownSample(),
+        EqualisedConv2d(256, 512, kernel_size=4, padding=1), _Slot("InstanceNorm2d"), _Slot("LeakyReLU(0.2)"),
+    ]
+
+
+def _run_trunk(mods, t):
+    t = mods[2].run(mods[0].run(t, act=H.ACT_LRELU))
+    t = mods[6].run(ops.instance_norm_act(mods[3].run(t), H.ACT_LRELU))
+    t = mods[10].run(ops.instance_norm_act(mods[7].run(t), H.ACT_LRELU))
+    return ops.instance_norm_act(mods[11].run(t), H.ACT_LRELU)
+
+
+class Discriminator(nn.Module):
+    """PatchGAN with stride-1 4x4 convs and blur-downsampling (reference builder.py:259-287)."""
+
+    def __init__(self, input_nc: int):
+        super().__init__()
+        self.model = nn.Sequential(*_patch_trunk(input_nc), EqualisedConv2d(512, 1, kernel_size=4, padding=1))
+
+    def forward(self, x: torch.Tensor):
+        t = _run_trunk(self.model, ops.to_internal(x))
+        return ops.to_public(self.model[14].run(t), 1)
+
+
+class StyleExtractor(nn.Module):
+    """Discriminator trunk -> global average pool -> linear (reference builder.py:293-320)."""
+
+    def __init__(self, input_nc: int = 1, w_dim: int = 8):
+        super().__init__()
+        self.model = nn.Sequential(*_patch_trunk(input_nc), _Slot("AdaptiveAvgPool2d(1)"), _Slot("Flatten"),
+                                   EqualisedLinear(512, w_dim))
+
+    def forward(self, x):
+        t = _run_trunk(self.model, ops.to_internal(x))
+        return self.model[16](t.float().mean(dim=(1, 2)))

@@ -1,0 +1,369 @@
+"""Autograd operators of the hot path, each a thin host wrapper over the C-ABI launchers in
+libo2m_hip.so (include/o2m_hip.h).  No op here has an eager/CPU fallback.
+
+Internal activation format ("internal tensors"): contiguous ``[B, H, W, Cp]`` (NHWC), ``Cp``
+a multiple of 8, dtype = the compute dtype (bf16, or fp32 in parity mode); channels beyond
+the logical count are exactly zero everywhere (zero weight rows / zero bias keep them so).
+Public tensors are logical NCHW views of those buffers (``to_public``), so the reference's
+module API (builder.py) is met without copies.
+"""
+
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import _hip as H
+from . import resample as R
+
+_STATE = {"dtype": torch.bfloat16, "epoch": 0}
+
+
+def set_precision(precision: str) -> None:
+    """"bf16": bf16 storage + bf16 MFMA (throughput mode, BASELINE config #2).
+    "fp32": fp32 storage + bf16x3 split MFMA (parity mode, <=1e-3 of the CPU reference)."""
+    if precision not in ("bf16", "fp32"):
+        raise ValueError(precision)
+    _STATE["dtype"] = torch.bfloat16 if precision == "bf16" else torch.float32
+
+
+def compute_dtype() -> torch.dtype:
+    return _STATE["dtype"]
+
+
+def bump_weights_epoch() -> None:
+    """Called by optimisers that update parameters behind autograd's back (fused Adam)."""
+    _STATE["epoch"] += 1
+
+
+def pad8(c: int) -> int:
+    return (c + 7) // 8 * 8
+
+
+# ------------------------------------------------------------------------ layout boundary
+
+
+def _as_internal_view(x: torch.Tensor):
+    """Zero-copy recovery of the internal buffer behind a public view, or None."""
+    if x.dim() != 4 or x.dtype != compute_dtype() or not x.is_cuda:
+        return None
+    b, c, h, w = x.shape
+    cp = pad8(c)
+    if x.stride() != (h * w * cp, 1, w * cp, cp) or x.storage_offset() % 8:
+        return None
+    return x.as_strided((b, h, w, cp), (h * w * cp, w * cp, cp, 1))
+
+
+def _pack(x: torch.Tensor) -> torch.Tensor:
+    v = _as_internal_view(x)
+    if v is not None:
+        return v
+    if not x.is_cuda:
+        raise RuntimeError("the one-to-many GAN hot path runs on the GPU only (no CPU fallback)")
+    b, c, h, w = x.shape
+    out = torch.empty((b, h, w, pad8(c)), dtype=compute_dtype(), device=x.device)
+    H.pack_nchw(x.detach().float().contiguous(), out)
+    return out
+
+
+class _ToInternal(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.c = x.shape[1]
+        return _pack(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.permute(0, 3, 1, 2)[:, : ctx.c]
+
+
+class _ToPublic(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t, c):
+        return t.permute(0, 3, 1, 2)[:, :c]
+
+    @staticmethod
+    def backward(ctx, g):
+        return _pack(g), None
+
+
+def to_internal(x: torch.Tensor) -> torch.Tensor:
+    """Logical NCHW tensor (any dtype/strides) -> internal NHWC buffer (zero-copy if it
+    already is a public view of one)."""
+    return _ToInternal.apply(x)
+
+
+def to_public(t: torch.Tensor, c: int) -> torch.Tensor:
+    """Internal NHWC buffer -> logical (B, c, H, W) view."""
+    return _ToPublic.apply(t, c)
+
+
+# ------------------------------------------------------------------------ prepared weights
+
+
+class PreparedWeight:
+    """Per-layer cache of the kernel-side forms of one equalised-LR filter
+    (layers.py:12-24): W*c cast to the compute dtype in [Co][KH][KW][Ci] (forward/wgrad
+    operand order), its flipped transpose [Ci][KH][KW][Co] (the data-gradient filter) and,
+    for modulated convs, Q[o,i] = c^2 * sum_k W[o,i,k]^2 (layers.py:156-161 factored so the
+    demodulation needs no per-sample weights).  Rebuilt when the parameter changes."""
+
+    def __init__(self, weight: torch.nn.Parameter, need_q: bool):
+        self.weight = weight
+        self.need_q = need_q
+        co, ci, kh, kw = weight.shape
+        self.co, self.ci, self.kh, self.kw = co, ci, kh, kw
+        self.cop, self.cip = pad8(co), pad8(ci)
+        self.c = 1.0 / math.sqrt(ci * kh * kw)
+        self._key = None
+        self._val = None
+
+    def get(self):
+        w = self.weight
+        key = (w._version, w.data_ptr(), _STATE["epoch"], compute_dtype())
+        if key != self._key:
+            with torch.no_grad():
+                ws = (w.detach().float() * self.c).permute(0, 2, 3, 1)  # [co,kh,kw,ci]
+                full = torch.zeros((self.cop, self.kh, self.kw, self.cip), dtype=torch.float32,
+                                   device=w.device)
+                full[: self.co, :, :, : self.ci] = ws
+                w_f = full.to(compute_dtype()).contiguous()
+                w_d = full.flip(1, 2).permute(3, 1, 2, 0).to(compute_dtype()).contiguous()
+                q = full.square().sum(dim=(1, 2)).contiguous() if self.need_q else None
+            self._val = (w_f, w_d, q)
+            self._key = key
+        return self._val
+
+
+def _pad_cols(t: torch.Tensor, n: int) -> torch.Tensor:
+    t = t.float()
+    if t.shape[1] == n:
+        return t.contiguous()
+    out = torch.zeros((t.shape[0], n), dtype=torch.float32, device=t.device)
+    out[:, : t.shape[1]] = t
+    return out
+
+
+# ---------------------------------------------------------------------------------- conv
+
+
+class _ConvFn(torch.autograd.Function):
+    """y = act(d[b,o] * conv(W*c, pad(x * s[b,i])) + bias) + residual, d = demodulation."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, style, residual, prep, pad, pad_mode, act, demodulate, eps):
+        w_f, w_d, q = prep.get()
+        B, Hh, Ww, cip = x.shape
+        if cip != prep.cip:
+            raise RuntimeError(f"conv input has {cip} channels, layer expects {prep.cip} (padded)")
+        ho, wo = Hh + 2 * pad - prep.kh + 1, Ww + 2 * pad - prep.kw + 1
+        s = d = None
+        if style is not None:
+            s = _pad_cols(style, prep.cip)
+            if demodulate:
+                d = torch.rsqrt(torch.addmm(torch.full((1, 1), eps, device=x.device), s * s, q.t()))
+                d = d.contiguous()
+        bias_p = None
+        if bias is not None:
+            bias_p = torch.zeros(prep.cop, dtype=torch.float32, device=x.device)
+            bias_p[: prep.co] = bias.detach().float()
+        y = torch.empty((B, ho, wo, prep.cop), dtype=x.dtype, device=x.device)
+        H.conv2d_fwd(x, w_f, y, in_scale=s, out_scale=d, bias=bias_p, residual=residual,
+                     pad=pad, pad_mode=pad_mode, act=act)
+        ctx.prep, ctx.pad, ctx.pad_mode, ctx.act = prep, pad, pad_mode, act
+        ctx.has_bias, ctx.has_res = bias is not None, residual is not None
+        ctx.save_for_backward(x, y, residual, s, d, weight, bias_p)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y, residual, s, d, weight, bias_p = ctx.saved_tensors
+        prep, pad, pad_mode, act = ctx.prep, ctx.pad, ctx.pad_mode, ctx.act
+        w_f, w_d, q = prep.get()
+        g = g.contiguous()
+        B, Hh, Ww, cip = x.shape
+        need_x, need_w, need_b, need_s = ctx.needs_input_grad[0:4]
+        need_res = ctx.needs_input_grad[4]
+
+        sums = None
+        if act != H.ACT_NONE or d is not None:
+            gu = torch.empty_like(g)
+            sums = torch.zeros((B, prep.cop, 2), dtype=torch.float32, device=g.device)
+            H.act_bwd_reduce(g, y, residual, gu, sums, act)  # u = y - residual = act(pre)
+        else:
+            gu = g
+
+        g_bias = None
+        if ctx.has_bias and need_b:
+            tot = sums[:, :, 0].sum(0) if sums is not None else gu.float().sum(dim=(0, 1, 2))
+            g_bias = tot[: prep.co].to(weight.dtype)
+
+        g_x = dots = None
+        if need_x or (need_s and s is not None):
+            kpad = prep.kh - 1 - (0 if pad_mode == H.PAD_REFLECT else pad)
+            hp = Hh + (2 * pad if pad_mode == H.PAD_REFLECT else 0)
+            wp = Ww + (2 * pad if pad_mode == H.PAD_REFLECT else 0)
+            gxp = torch.empty((B, hp, wp, cip), dtype=g.dtype, device=g.device)
+            H.conv2d_fwd(gu, w_d, gxp, in_scale=d, pad=kpad, pad_mode=H.PAD_ZERO, act=H.ACT_NONE)
+            if s is not None or pad_mode == H.PAD_REFLECT:
+                g_x = torch.empty_like(x)
+                if s is not None:
+                    dots = torch.zeros((B, cip), dtype=torch.float32, device=g.device)
+                H.fold_scale_dot(gxp, x if s is not None else None, s, g_x, dots,
+                                 pad if pad_mode == H.PAD_REFLECT else 0)
+            else:
+                g_x = gxp
+
+        g_w = e = None
+        if need_w:
+            dw = torch.zeros((prep.cop, prep.kh, prep.kw, cip), dtype=torch.float32, device=g.device)
+            H.conv2d_wgrad(x, gu, dw, in_scale=s, gy_scale=d, pad=pad, pad_mode=pad_mode)
+            g_w = dw[: prep.co, :, :, : prep.ci].permute(0, 3, 1, 2) * prep.c
+        g_s = None
+        if d is not None and (need_w or need_s):
+            # demodulation chain: d = (s^2 Q^T + eps)^(-1/2);  dL/dd = sums[...,1] / d
+            # sum_p gu*z with z = (u - bias)/d  ->  dL/d(s^2 Q^T) = -(1/2) d^3 * that
+            s1 = sums[:, :, 1] if bias_p is None else sums[:, :, 1] - bias_p * sums[:, :, 0]
+            e = s1 * (-0.5) * d * d
+            if need_w:
+                gq = e.t() @ (s * s)  # [cop, cip]
+                g_w = g_w + gq[: prep.co, : prep.ci, None, None] * (2.0 * prep.c * prep.c) * weight.detach().float()
+        if need_s and s is not None:
+            g_s = dots
+            if e is not None:
+                g_s = g_s + 2.0 * s * (e @ q)
+            g_s = g_s[:, : prep.ci]
+        if g_w is not None:
+            g_w = g_w.to(weight.dtype).contiguous()
+        g_res = g if (ctx.has_res and need_res) else None
+        return (g_x if need_x else None, g_w, g_bias, g_s, g_res, None, None, None, None, None, None)
+
+
+def conv2d(x, weight, bias, prep, *, pad, pad_mode=H.PAD_ZERO, act=H.ACT_NONE, style=None,
+           residual=None, demodulate=True, eps=1e-8):
+    return _ConvFn.apply(x, weight, bias, style, residual, prep, pad, pad_mode, act, demodulate, eps)
+
+
+# --------------------------------------------------------------------------- instance norm
+
+
+class _InstNormFn(torch.autograd.Function):
+    """y = act(InstanceNorm2d(x)) + residual  (eps 1e-5, biased variance, no affine)."""
+
+    @staticmethod
+    def forward(ctx, x, residual, act, eps):
+        B, Hh, Ww, Cn = x.shape
+        ws = torch.empty(H.instnorm_ws_floats(B, Hh * Ww, Cn), dtype=torch.float32, device=x.device)
+        mr = torch.empty((B, Cn, 2), dtype=torch.float32, device=x.device)
+        H.instnorm_stats(x, ws, mr, eps)
+        y = torch.empty_like(x)
+        H.instnorm_apply(x, mr, residual, y, act)
+        ctx.act = act
+        ctx.save_for_backward(x, mr)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, mr = ctx.saved_tensors
+        g = g.contiguous()
+        B, Hh, Ww, Cn = x.shape
+        gx = None
+        if ctx.needs_input_grad[0]:
+            ws = torch.empty(H.instnorm_ws_floats(B, Hh * Ww, Cn), dtype=torch.float32, device=x.device)
+            gs = torch.empty((B, Cn, 2), dtype=torch.float32, device=x.device)
+            gx = torch.empty_like(x)
+            H.instnorm_bwd(g, x, mr, ws, gs, gx, ctx.act)
+        return gx, (g if ctx.needs_input_grad[1] else None), None, None
+
+
+def instance_norm_act(x, act=H.ACT_NONE, residual=None, eps=1e-5):
+    return _InstNormFn.apply(x, residual, act, eps)
+
+
+# -------------------------------------------------------------------------------- resample
+
+
+class _ResampleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, kind):
+        B, Hh, Ww, Cn = x.shape
+        sy, wy, sx, wx, T, ho, wo = R.taps(kind, Hh, Ww, False, x.device)
+        y = torch.empty((B, ho, wo, Cn), dtype=x.dtype, device=x.device)
+        H.resample2d(x, y, sy, wy, sx, wx, T)
+        ctx.kind, ctx.hw = kind, (Hh, Ww)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        Hh, Ww = ctx.hw
+        sy, wy, sx, wx, T, ho, wo = R.taps(ctx.kind, Hh, Ww, True, g.device)
+        gx = torch.empty((g.shape[0], ho, wo, g.shape[3]), dtype=g.dtype, device=g.device)
+        H.resample2d(g, gx, sy, wy, sx, wx, T)
+        return gx, None
+
+
+def resample(x, kind):
+    """kind in {"blur", "up", "down"} (Smooth / UpSample / DownSample of layers.py)."""
+    return _ResampleFn.apply(x, kind)
+
+
+# ---------------------------------------------------------------------------------- losses
+
+
+def _partials(n_elems, n_out, device):
+    return torch.empty(n_out * H.reduce_blocks(n_elems), dtype=torch.float32, device=device)
+
+
+class _PairReduceFn(torch.autograd.Function):
+    """sum over all elements of |a-b| (L1) or w[b]*(a-b)^2 (SQ); returns an fp32 scalar."""
+
+    @staticmethod
+    def forward(ctx, a, b, w, mode):
+        part = _partials(a.numel(), 1, a.device)
+        H.reduce_fwd(a, b, w, part, mode)
+        ctx.mode = mode
+        ctx.save_for_backward(a, b, w)
+        return part.sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b, w = ctx.saved_tensors
+        coef = (g.float() * (2.0 if ctx.mode == H.RED_SQ else 1.0)).reshape(1).contiguous()
+        ga = torch.empty_like(a)
+        H.reduce_bwd(a, b, w, coef, ga, ctx.mode)
+        gb = -ga if (b is not None and ctx.needs_input_grad[1]) else None
+        return (ga if ctx.needs_input_grad[0] else None), gb, None, None
+
+
+class _MomentsFn(torch.autograd.Function):
+    """(sum a, sum a^2) as fp32 scalars (kl_loss_func, loss.py:86-87)."""
+
+    @staticmethod
+    def forward(ctx, a):
+        nb = H.reduce_blocks(a.numel())
+        part = _partials(a.numel(), 2, a.device)
+        H.reduce_fwd(a, None, None, part, H.RED_MOM)
+        ctx.save_for_backward(a)
+        return part[:nb].sum(), part[nb:].sum()
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        (a,) = ctx.saved_tensors
+        coef = torch.stack([g1.float(), 2.0 * g2.float()]).contiguous()
+        ga = torch.empty_like(a)
+        H.reduce_bwd(a, None, None, coef, ga, H.RED_MOM)
+        return ga
+
+
+def l1_sum(a, b):
+    return _PairReduceFn.apply(a, b, None, H.RED_L1)
+
+
+def sq_sum(a, b=None, w=None):
+    return _PairReduceFn.apply(a, b, w, H.RED_SQ)
+
+
+def moments(a):
+    return _MomentsFn.apply(a)

@@ -1,0 +1,123 @@
+"""Host-side construction of the 1-D banded operators behind Smooth / UpSample / DownSample.
+
+All three reference layers (layers.py:191-247) are separable linear maps
+``Y = A_h . X . A_w^T``:
+
+* blur      : replicate-pad 1 then [1,2,1]/4 per axis             (layers.py:197-214)
+* bilinear  : align_corners=False, src = (i+0.5)*in/out - 0.5      (layers.py:223-229,241-247)
+* UpSample  = blur(2n) . bilinear(n -> 2n);  DownSample = bilinear(n -> n//2) . blur(n)
+  (odd n gives the fractional taps of scale n / floor(n/2)).
+
+The device kernel (o2m_resample2d) applies any such operator given per-output-row taps
+``(start, weights[T])``; the backward pass is the same kernel with the transposed operator.
+Host logic only (numpy); tested on CPU against F.interpolate / the oracle.
+"""
+
+from __future__ import annotations
+
+import functools
+
+import numpy as np
+import torch
+
+
+def blur_matrix(n: int) -> np.ndarray:
+    a = np.zeros((n, n), dtype=np.float64)
+    for i in range(n):
+        a[i, max(i - 1, 0)] += 0.25
+        a[i, i] += 0.5
+        a[i, min(i + 1, n - 1)] += 0.25
+    return a
+
+
+def bilinear_matrix(n_in: int, n_out: int, scale: float | None = None) -> np.ndarray:
+    """Rows follow ATen's upsample_bilinear2d (align_corners=False), evaluated in fp32."""
+    sc = np.float32(n_in / n_out if scale is None else scale)
+    a = np.zeros((n_out, n_in), dtype=np.float64)
+    for i in range(n_out):
+        src = sc * np.float32(i + 0.5) - np.float32(0.5)
+        if src < 0:
+            src = np.float32(0.0)
+        i0 = min(int(np.floor(src)), n_in - 1)
+        i1 = min(i0 + 1, n_in - 1)
+        lam = np.float32(src - np.float32(i0))
+        a[i, i0] += float(np.float32(1.0) - lam)
+        a[i, i1] += float(lam)
+    return a
+
+
+def operator_matrix(kind: str, n: int) -> np.ndarray:
+    if kind == "blur":
+        return blur_matrix(n)
+    if kind == "up":
+        return blur_matrix(2 * n) @ bilinear_matrix(n, 2 * n, scale=0.5)
+    if kind == "down":
+        return bilinear_matrix(n, n // 2) @ blur_matrix(n)
+    if kind == "down_nosmooth":  # DownSample(smooth=False), layers.py:235-247
+        return bilinear_matrix(n, n // 2)
+    raise ValueError(kind)
+
+
+def banded(a: np.ndarray):
+    """Dense operator -> (start int32 [rows], weights fp32 [rows][T], T)."""
+    rows, cols = a.shape
+    first = np.zeros(rows, dtype=np.int64)
+    width = 1
+    for r in range(rows):
+        nz = np.nonzero(a[r])[0]
+        if nz.size:
+            first[r] = nz[0]
+            width = max(width, int(nz[-1] - nz[0] + 1))
+    width = min(width, cols)
+    start = np.minimum(first, cols - width)
+    w = np.zeros((rows, width), dtype=np.float32)
+    for r in range(rows):
+        w[r] = a[r, start[r]: start[r] + width]
+    return start.astype(np.int32), w, width
+
+
+@functools.lru_cache(maxsize=256)
+def _taps_host(kind: str, n: int, transposed: bool):
+    a = operator_matrix(kind, n)
+    if transposed:
+        a = a.T
+    return banded(np.ascontiguousarray(a))
+
+
+_dev_cache: dict = {}
+
+
+def taps(kind: str, n_h: int, n_w: int, transposed: bool, device):
+    """Device-resident taps for both axes, padded to a common T."""
+    key = (kind, n_h, n_w, transposed, str(device))
+    hit = _dev_cache.get(key)
+    if hit is not None:
+        return hit
+    sy, wy, ty = _taps_host(kind, n_h, transposed)
+    sx, wx, tx = _taps_host(kind, n_w, transposed)
+    T = max(ty, tx)
+
+    def fit(s, w, t, n_src):
+        if t == T:
+            return s, w
+        # widen to T taps, keeping every tap inside the source
+        s2 = np.minimum(s, max(n_src - T, 0)).astype(np.int32)
+        w2 = np.zeros((w.shape[0], T), dtype=np.float32)
+        for r in range(w.shape[0]):
+            w2[r, s[r] - s2[r]: s[r] - s2[r] + t] = w[r]
+        return s2, w2
+
+    a_h = operator_matrix(kind, n_h)
+    a_w = operator_matrix(kind, n_w)
+    src_h = a_h.shape[0] if transposed else a_h.shape[1]
+    src_w = a_w.shape[0] if transposed else a_w.shape[1]
+    sy, wy = fit(sy, wy, ty, src_h)
+    sx, wx = fit(sx, wx, tx, src_w)
+    out_h, out_w = wy.shape[0], wx.shape[0]
+    res = (
+        torch.from_numpy(sy).to(device), torch.from_numpy(np.ascontiguousarray(wy)).to(device),
+        torch.from_numpy(sx).to(device), torch.from_numpy(np.ascontiguousarray(wx)).to(device),
+        T, out_h, out_w,
+    )
+    _dev_cache[key] = res
+    return res

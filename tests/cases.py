@@ -32,13 +32,14 @@ def _grads(module, out, tag):
             out[f"g/{name}"] = _cpu(p.grad)
 
 
-def _run_op(module, inputs, tag, device, call=None):
+def _run_op(module, inputs, tag, device, call=None, wrap=None):
     """Forward + backward of one module under the fixed linear loss sum(y * r)."""
     module = module.to(device)
+    target = wrap(module) if wrap else module
     xs = [x.to(device).requires_grad_(True) for x in inputs]
-    y = call(module, *xs) if call else module(*xs)
+    y = call(target, *xs) if call else target(*xs)
     r = sym_uniform(f"{tag}/r", y.shape).to(device)
-    (y * r).sum().backward()
+    (y.float() * r).sum().backward()
     out = OrderedDict(y=_cpu(y))
     for i, x in enumerate(xs):
         out[f"gx{i}"] = _cpu(x.grad)
@@ -54,10 +55,9 @@ def case_conv(ns, device, *, tag, cin, cout, k, pad, bias, n, h, w, reflect=0):
     fill_state_dict(m, tag)
     x = image_batch(f"{tag}/x", (n, cin, h, w))
     if reflect:
+        if hasattr(ns, "conv_reflect"):  # padding fused into the conv loader
+            return _run_op(m, [x], tag, device, wrap=lambda mod: ns.conv_reflect(mod, reflect))
         call = lambda mod, t: mod(torch.nn.functional.pad(t, (reflect,) * 4, mode="reflect"))  # noqa: E731
-        if hasattr(ns, "conv_reflect"):
-            m = ns.conv_reflect(m, reflect)
-            call = None
         return _run_op(m, [x], tag, device, call)
     return _run_op(m, [x], tag, device)
 
@@ -68,10 +68,9 @@ def case_modconv(ns, device, *, tag, cin, cout, k, pad, wdim, n, h, w, reflect=0
     x = image_batch(f"{tag}/x", (n, cin, h, w))
     s = unit_uniform(f"{tag}/w", (n, wdim))  # mapping-net outputs are >= 0
     if reflect:
-        call = lambda mod, t, wv: mod(torch.nn.functional.pad(t, (reflect,) * 4, mode="reflect"), wv)  # noqa: E731
         if hasattr(ns, "modconv_reflect"):
-            m = ns.modconv_reflect(m, reflect)
-            call = None
+            return _run_op(m, [x, s], tag, device, wrap=lambda mod: ns.modconv_reflect(mod, reflect))
+        call = lambda mod, t, wv: mod(torch.nn.functional.pad(t, (reflect,) * 4, mode="reflect"), wv)  # noqa: E731
         return _run_op(m, [x, s], tag, device, call)
     return _run_op(m, [x, s], tag, device)
 
@@ -132,7 +131,7 @@ def case_generator(ns, device, *, tag, nc, size, min_latent, n_res, start_filter
     for i, f in enumerate(feats):
         _put(out, f"feat{i}", f)
     r = sym_uniform(f"{tag}/r", img.shape).to(device)
-    loss = (img * r).sum() + sum((f * f).mean() for f in feats)
+    loss = (img.float() * r).sum() + sum((f.float() ** 2).mean() for f in feats)
     loss.backward()
     _put(out, "gx", x.grad)
     out["gw"] = _cpu(w.grad)
@@ -151,7 +150,7 @@ def case_patchnet(ns, device, *, tag, kind, nc, size, n, wdim=6):
     x = image_batch(f"{tag}/x", (n, nc, size, size)).to(device).requires_grad_(True)
     y = net(x)
     r = sym_uniform(f"{tag}/r", y.shape).to(device)
-    (y * r).sum().backward()
+    (y.float() * r).sum().backward()
     out = OrderedDict()
     _put(out, "y", y)
     _put(out, "gx", x.grad)

@@ -1,0 +1,159 @@
+"""CPU tests of the host-side logic of the product package (no GPU, no HIP calls)."""
+
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import model as om
+from oracle import training as ot
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    """The C-ABI library must load on a CPU-only box and export exactly the entry points
+    include/o2m_hip.h declares (no compute calls here)."""
+    from one_to_many_gan_amd import _hip
+
+    header = open(os.path.join(ROOT, "include", "o2m_hip.h")).read()
+    declared = set(re.findall(r"\b(o2m_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(_hip.SIGNATURES), declared ^ set(_hip.SIGNATURES)
+    lib = _hip.lib()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.o2m_abi_version() == _hip.ABI_VERSION
+    assert lib.o2m_reduce_blocks(8 * 2048 * 3 + 8) == 4
+    assert lib.o2m_instnorm_ws_floats(2, 100, 16) > 0
+
+
+def test_struct_layouts_match_header():
+    from one_to_many_gan_amd import _hip
+
+    assert ctypes.sizeof(_hip.ConvDesc) == 7 * 8 + 16 * 4
+    assert ctypes.sizeof(_hip.WgradDesc) == 5 * 8 + 16 * 4
+
+
+def test_hot_path_fails_loudly_without_gpu():
+    import one_to_many_gan_amd as pk
+    from one_to_many_gan_amd.model import layers
+
+    pk.set_precision("fp32")
+    conv = layers.EqualisedConv2d(8, 8, 3, padding=1)
+    with pytest.raises(RuntimeError, match="GPU"):
+        conv(torch.zeros(1, 8, 5, 5))
+
+
+@pytest.mark.parametrize("n", [4, 7, 8, 15, 31, 62, 63, 126, 255])
+def test_banded_operators_match_torch(n):
+    from one_to_many_gan_amd import resample as R
+
+    eye = torch.eye(n, dtype=torch.float64).view(1, n, n, 1).float()  # each column = basis vector
+    for kind, fn in (("blur", om.f_blur), ("up", om.f_upsample), ("down", om.f_downsample)):
+        if kind == "down" and n < 2:
+            continue
+        # apply the oracle op along H to the identity: column j of the result = A[:, j]
+        x = torch.eye(n).view(1, 1, n, n).repeat(1, 1, 1, 1)
+        # use a separable probe: f(e_i e_j^T) summed over j gives A e_i * (A 1)^T; instead build A from 1-D probes
+        cols = []
+        for j in range(n):
+            probe = torch.zeros(1, 1, n, 3)
+            probe[0, 0, j, :] = 1.0  # constant along W: W-operator rows sum to 1
+            out = fn(probe)
+            cols.append(out[0, 0, :, 0])
+        a_ref = torch.stack(cols, 1).double().numpy()
+        a = R.operator_matrix(kind, n)
+        assert a.shape == a_ref.shape
+        assert np.abs(a - a_ref).max() < 2e-6, kind
+        start, w, T = R.banded(a)
+        dense = np.zeros_like(a)
+        for r in range(a.shape[0]):
+            dense[r, start[r]: start[r] + T] = w[r]
+        assert np.abs(dense - a).max() < 1e-7
+        assert (start >= 0).all() and (start + T <= a.shape[1]).all()
+        st, wt, Tt = R.banded(np.ascontiguousarray(a.T))
+        dense_t = np.zeros_like(a.T)
+        for r in range(a.shape[1]):
+            dense_t[r, st[r]: st[r] + Tt] = wt[r]
+        assert np.abs(dense_t - a.T).max() < 1e-7
+
+
+def test_adap_and_imagebuffer_match_oracle():
+    import random
+
+    from one_to_many_gan_amd.core.training import ImageBuffer
+    from one_to_many_gan_amd.model.loss import ADAp
+
+    a, b = ADAp(256, 5.12e-4, 4, 0.6), ot.ADAp(256, 5.12e-4, 4, 0.6)
+    g = torch.Generator().manual_seed(3)
+    for i in range(400):
+        v = torch.rand((), generator=g) * 2 - (1.0 if i < 200 else 0.2)
+        a.update_p(v)
+        b.update_p(v)
+        assert a() == b()
+    assert a() > 0  # the schedule moved
+    with pytest.raises(ValueError):
+        ImageBuffer(0)
+    for cls in (ImageBuffer, ot.ImageBuffer):
+        random.seed(5)
+        buf = cls(3)
+        outs = [buf(torch.arange(4.0).view(4, 1, 1, 1) + 4 * s)[:, 0, 0, 0] for s in range(6)]
+        if cls is ImageBuffer:
+            mine = torch.stack(outs)
+        else:
+            assert torch.equal(mine, torch.stack(outs))
+
+
+def test_mapping_network_rng_order_matches_oracle():
+    from one_to_many_gan_amd.model.builder import MappingNetwork
+    from oracle.detweights import fill_state_dict
+
+    a, b = MappingNetwork(6, 2, 0.9), om.MappingNetwork(6, 2, 0.9)
+    fill_state_dict(a, "m")
+    fill_state_dict(b, "m")
+    for net in (a, b):
+        torch.manual_seed(11)
+        outs = [net.get_single_w(3, 6, torch.device("cpu"), 1) for _ in range(6)]
+        d = (torch.tensor([0.2, 0.5, 0.9]), torch.tensor([0.1, 0.4, 1.0]))
+        outs += list(net.get_two_w(3, 6, torch.device("cpu"), d))
+        outs.append(net.get_single_w(3, 6, torch.device("cpu"), 0))
+        if net is a:
+            mine = outs
+        else:
+            for x, y in zip(mine, outs):
+                assert torch.allclose(x, y, atol=1e-6)
+    assert torch.all(a(torch.randn(4, 6)) >= 0)  # final ReLU: styles are non-negative
+
+
+def test_state_dict_keys_match_oracle_layout():
+    """Same keys/shapes as the reference layout so checkpoints load."""
+    from one_to_many_gan_amd.model import builder as pb
+
+    pairs = [
+        (pb.Generator(3, 6, (64, 64), 16, 5, 8), om.Generator(3, 6, (64, 64), 16, 5, 8)),
+        (pb.Discriminator(3), om.Discriminator(3)),
+        (pb.StyleExtractor(3, 6), om.StyleExtractor(3, 6)),
+        (pb.MappingNetwork(6, 2, 0.9), om.MappingNetwork(6, 2, 0.9)),
+    ]
+    for mine, ref in pairs:
+        a, b = mine.state_dict(), ref.state_dict()
+        assert list(a) == list(b)
+        for k in a:
+            assert a[k].shape == b[k].shape, k
+        mine.load_state_dict(b)
+    g = pairs[0][0]
+    assert g.n_style_blocks == pairs[0][1].n_style_blocks
+
+
+def test_losses_small_torch_parts_match_oracle():
+    from one_to_many_gan_amd.model.loss import style_cycle_loss_func
+
+    a, b = torch.randn(5, 6), torch.randn(5, 6)
+    assert torch.allclose(style_cycle_loss_func(a, b), ot.style_cycle_loss_func(a, b), atol=1e-6)
+    assert torch.allclose(style_cycle_loss_func(a, b, normalise=False, cos_l2_ratio=0.5),
+                          ot.style_cycle_loss_func(a, b, normalise=False, cos_l2_ratio=0.5), atol=1e-6)
