@@ -31,16 +31,19 @@ __device__ __forceinline__ int tile_off(int row, int chunk) {
 
 template <typename T> struct Stg;  // staged registers for 8 consecutive reduction elements
 template <> struct Stg<unsigned short> { u32x4 v; };
-template <> struct Stg<float> { u32x4 v[2]; };
+template <> struct Stg<float> { f32x4 a, b; };
 
 __device__ __forceinline__ void stg_zero(Stg<unsigned short>& s) { s.v = u32x4{0, 0, 0, 0}; }
-__device__ __forceinline__ void stg_zero(Stg<float>& s) { s.v[0] = s.v[1] = u32x4{0, 0, 0, 0}; }
+__device__ __forceinline__ void stg_zero(Stg<float>& s) {
+  s.a = f32x4{0.f, 0.f, 0.f, 0.f};
+  s.b = f32x4{0.f, 0.f, 0.f, 0.f};
+}
 __device__ __forceinline__ void stg_load(Stg<unsigned short>& s, const unsigned short* p) {
   s.v = *reinterpret_cast<const u32x4*>(p);
 }
 __device__ __forceinline__ void stg_load(Stg<float>& s, const float* p) {
-  s.v[0] = *reinterpret_cast<const u32x4*>(p);
-  s.v[1] = *reinterpret_cast<const u32x4*>(p + 4);
+  s.a = *reinterpret_cast<const f32x4*>(p);
+  s.b = *reinterpret_cast<const f32x4*>(p + 4);
 }
 __device__ __forceinline__ void stg_unpack(const Stg<unsigned short>& s, float (&f)[8]) {
 #pragma unroll
@@ -52,8 +55,8 @@ __device__ __forceinline__ void stg_unpack(const Stg<unsigned short>& s, float (
 __device__ __forceinline__ void stg_unpack(const Stg<float>& s, float (&f)[8]) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    f[i] = __builtin_bit_cast(float, s.v[0][i]);
-    f[4 + i] = __builtin_bit_cast(float, s.v[1][i]);
+    f[i] = s.a[i];
+    f[4 + i] = s.b[i];
   }
 }
 

@@ -1,0 +1,36 @@
+"""Print per-tensor relative errors of the HIP path against the reference fixtures.
+Usage: python tools/parity_report.py [--prec fp32,bf16] [case ...]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+from tests.cases import CASES, run_case
+from tests.namespaces import product_ns
+
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+precs = ["fp32", "bf16"]
+for a in sys.argv[1:]:
+    if a.startswith("--prec="):
+        precs = a.split("=")[1].split(",")
+names = args or [n for n in CASES if not n.startswith("steps")]
+for name in names:
+    gold = np.load(os.path.join(ROOT, "tests", "golden", f"{name}.npz"))
+    for prec in precs:
+        t0 = time.time()
+        try:
+            got = run_case(name, product_ns(prec), "cuda")
+        except Exception as e:  # noqa: BLE001
+            print(f"{name} [{prec}] EXCEPTION {type(e).__name__}: {e}")
+            continue
+        worst = []
+        for k in gold.files:
+            w = torch.from_numpy(gold[k]).double().flatten()
+            g = got[k].double().flatten()
+            if k.endswith("/sum") or k.endswith("/sqsum"):
+                continue
+            err = float((g - w).norm() / (w.norm() + 1e-30))
+            worst.append((err, k))
+        worst.sort(reverse=True)
+        top = ", ".join(f"{k}={e:.2e}" for e, k in worst[:6])
+        print(f"{name:18s} [{prec}] {time.time()-t0:5.1f}s max={worst[0][0]:.2e} | {top}", flush=True)
