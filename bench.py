@@ -1,0 +1,263 @@
+#!/usr/bin/env python3
+"""Benchmark of the one-to-many GAN hot path: one step = discriminator_step +
+generator_step on synthetic 256x256 RGB batches (BASELINE.json configs[1]: B = 16 per GPU,
+bf16), weak-scaled data parallel over N GPUs of one node.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task description): images/sec over the whole
+job, plus `roofline` (dominant kernel, live HIP-event timing, achieved fraction of the dense
+bf16 MFMA peak) and, at N = 1, `cpu_baseline` (the CPU oracle timed on the host cores on a
+bounded sample of the same workload).
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FLOP_PER_IMAGE_STEP = {(256, 3): 1461.40e9, (512, 3): 6762.64e9, (64, 1): 60.19e9}
+MFMA_PEAK = {"bf16": 2.5e15, "fp32": 2.5e15 / 3}  # dense bf16 MFMA; fp32 mode issues 3 MFMAs/product
+
+
+def make_config(size, channels, batch):
+    return {
+        "training": {"batch_size": batch, "random_seed": 42, "training_steps": 150000,
+                     "image_buffer_size": 100, "style_mixing_prob": 0.9,
+                     "deterministic_cuda_kernels": False, "gpu_number": 0},
+        "optimisation": {"style_cycle_loss_lambda": 5.0, "identity_loss_lambda": 5.0,
+                         "reconstruction_loss_lambda": 5.0, "kl_loss_lambda": 0.01,
+                         "path_loss_lambda": 0.1, "path_loss_jacobian_granularity": [0.1, 0.2],
+                         "learning_rate": 2e-3, "mapping_network_learning_rate": 2e-5,
+                         "adam_betas": [0.5, 0.99]},
+        "ada": {"discriminator_real_acc_target": 0.6, "ada_overfitting_measurement_n_images": 256,
+                "ada_adjustment_size": 5.12e-4},
+        "architecture": {"w_dim": 6, "add_latent_noise": False, "min_latent_resolution": 64,
+                         "n_resnet_blocks": 7, "mapping_network_layers": 2},
+        "data": {"image_size": [size, size], "image_channels": channels},
+    }
+
+
+def synthetic_stream(seed, batch, channels, size, device, n_distinct=4):
+    """Endless stream of image batches in [-1,1), pre-staged on `device` (no DataLoader)."""
+    g = torch.Generator().manual_seed(seed)
+    pool = [(torch.rand(batch, channels, size, size, generator=g) * 2 - 1).to(device) for _ in range(n_distinct)]
+    i = 0
+    while True:
+        yield pool[i % n_distinct]
+        i += 1
+
+
+class Trainer:
+    """Everything train.py:72-116,171-195 builds, for either code base."""
+
+    def __init__(self, ns, cfg, device, seed_offset=0):
+        a, t, d, o = cfg["architecture"], cfg["training"], cfg["data"], cfg["optimisation"]
+        torch.manual_seed(t["random_seed"])
+        self.ns, self.cfg, self.device = ns, cfg, device
+        self.D = ns.Discriminator(d["image_channels"]).to(device)
+        self.G = ns.Generator(d["image_channels"], a["w_dim"], tuple(d["image_size"]),
+                              a["min_latent_resolution"], a["n_resnet_blocks"]).to(device)
+        self.M = ns.MappingNetwork(a["w_dim"], a["mapping_network_layers"], t["style_mixing_prob"]).to(device)
+        self.S = ns.StyleExtractor(d["image_channels"], a["w_dim"]).to(device)
+        betas = tuple(o["adam_betas"])
+        self.oD = ns.make_adam(self.D, o["learning_rate"], betas)
+        self.oG = ns.make_adam(self.G, o["learning_rate"], betas)
+        self.oM = ns.make_adam(self.M, o["mapping_network_learning_rate"], betas)
+        self.oS = ns.make_adam(self.S, o["learning_rate"], betas)
+        b = t["batch_size"]
+        self.prints = synthetic_stream(1000 + seed_offset, b, d["image_channels"], d["image_size"][0], device)
+        self.marks = synthetic_stream(2000 + seed_offset, b, d["image_channels"], d["image_size"][0], device)
+        self.buffer = ns.ImageBuffer(t["image_buffer_size"])
+        self.ada = ns.make_ada().to(device)
+        self.ada_p = ns.ADAp(cfg["ada"]["ada_overfitting_measurement_n_images"], cfg["ada"]["ada_adjustment_size"],
+                             b, cfg["ada"]["discriminator_real_acc_target"])
+        self.kl_hook = None
+        torch.manual_seed(t["random_seed"] + 1 + seed_offset)  # z / theta / h streams differ per rank
+
+    def step(self):
+        """The loop body of train.py:204-251."""
+        self.ada.set_p(self.ada_p())
+        d_out = self.ns.discriminator_step(self.cfg, self.device, self.D, self.G, self.M, self.oD,
+                                           self.prints, self.marks, self.buffer, self.ada, self.ada_p)
+        kw = {"kl_moment_hook": self.kl_hook} if self.kl_hook is not None else {}
+        g_out = self.ns.generator_step(self.cfg, self.device, self.G, self.D, self.M, self.S, self.oG,
+                                       self.oM, self.oS, self.prints, self.marks, self.ada, **kw)
+        return d_out, g_out
+
+
+def product_namespace(precision):
+    from types import SimpleNamespace
+
+    import one_to_many_gan_amd as pk
+    from one_to_many_gan_amd.core import training as pt
+    from one_to_many_gan_amd.model import builder as pb
+    from one_to_many_gan_amd.model import loss as pl
+
+    pk.set_precision(precision)
+    return SimpleNamespace(Discriminator=pb.Discriminator, Generator=pb.Generator,
+                           MappingNetwork=pb.MappingNetwork, StyleExtractor=pb.StyleExtractor,
+                           make_adam=pk.make_adam, ImageBuffer=pt.ImageBuffer, ADAp=pl.ADAp,
+                           make_ada=pk.IdentityADA, discriminator_step=pt.discriminator_step,
+                           generator_step=pt.generator_step)
+
+
+def oracle_namespace():
+    """CPU baseline leg only: the oracle is the checker / reported baseline, never shipped."""
+    from types import SimpleNamespace
+
+    from oracle import model as om
+    from oracle import training as ot
+
+    return SimpleNamespace(Discriminator=om.Discriminator, Generator=om.Generator,
+                           MappingNetwork=om.MappingNetwork, StyleExtractor=om.StyleExtractor,
+                           make_adam=lambda net, lr, betas: torch.optim.Adam(net.parameters(), lr=lr, betas=betas),
+                           ImageBuffer=ot.ImageBuffer, ADAp=ot.ADAp, make_ada=ot.IdentityADA,
+                           discriminator_step=ot.discriminator_step, generator_step=ot.generator_step)
+
+
+def kernel_profile(trainer, precision):
+    """One extra (untimed) step with a HIP-event pair around every MFMA conv launch, on the
+    stream the kernels are launched on.  Returns the dominant kernel's aggregate."""
+    from one_to_many_gan_amd import _hip
+
+    _hip.PROFILE = []
+    trainer.step()
+    torch.cuda.synchronize()
+    records, _hip.PROFILE = _hip.PROFILE, None
+    agg = {}
+    for name, flops, e0, e1 in records:
+        a = agg.setdefault(name, [0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += e0.elapsed_time(e1) * 1e-3
+        a[2] += flops
+    if not agg:
+        return None
+    total_conv_s = sum(a[1] for a in agg.values())
+    name, (n, secs, flops) = max(agg.items(), key=lambda kv: kv[1][1])
+    achieved = flops / secs / 1e12
+    peak = MFMA_PEAK[precision] / 1e12
+    return {
+        "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+        "frac": round(achieved / peak, 4), "traffic": None,
+        "kernel": name, "launches_per_step": n, "avg_launch_us": round(secs / n * 1e6, 2),
+        "share_of_conv_time": round(secs / total_conv_s, 3),
+        "all_conv_kernels": {k: {"launches": v[0], "ms": round(v[1] * 1e3, 3),
+                                 "tflops": round(v[2] / v[1] / 1e12, 1)} for k, v in sorted(agg.items())},
+    }
+
+
+def cpu_baseline(size, channels):
+    """The CPU oracle (a restatement of the reference's own CPU path, pinned against it) on a
+    bounded sample: one D+G step at B = 2 of the same 256x256 workload."""
+    cores = min(len(os.sched_getaffinity(0)), 16)  # the GPU box gives one GPU a 16-core share
+    torch.set_num_threads(cores)
+    b = 2
+    tr = Trainer(oracle_namespace(), make_config(size, channels, b), torch.device("cpu"))
+    t0 = time.perf_counter()
+    tr.step()
+    dt = time.perf_counter() - t0
+    return {"value": round(b / dt, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 D+G step (no warm-up) at batch {b}, {size}x{size}x{channels}, fp32, CPU oracle",
+            "seconds": round(dt, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--channels", type=int, default=3)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-profile", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    cfg = make_config(args.size, args.channels, args.batch)
+    trainer = Trainer(product_namespace(args.precision), cfg, device, seed_offset=rank)
+    if world > 1:
+        from one_to_many_gan_amd import dist as o2m_dist
+
+        opts = [trainer.oD, trainer.oG, trainer.oM, trainer.oS]
+        o2m_dist.broadcast_parameters(opts)
+        reducers = [o2m_dist.BucketReducer(o) for o in opts]
+        trainer.kl_hook = o2m_dist.make_kl_moment_hook()
+    else:
+        reducers = []
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = trainer.step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    images_per_sec = args.batch * world * args.steps / elapsed
+    flop = FLOP_PER_IMAGE_STEP.get((args.size, args.channels))
+    out = {
+        "metric": "images/sec (whole node), 256x256 G+D train step",
+        "value": round(images_per_sec, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.precision, "data": "synthetic",
+        "config": {"workload": f"{args.size}x{args.size}x{args.channels} D+G step (discriminator_step + "
+                               f"generator_step), batch {args.batch}/GPU, stock config.toml hyper-parameters, "
+                               "ADA at p=0", "global_batch": args.batch * world,
+                   "parallelism": f"dp{world}", "last_losses": {"d": last[0][0], "g": last[1][0]}},
+    }
+    if flop:
+        out["step_mfma_frac"] = round(images_per_sec * flop / (world * MFMA_PEAK[args.precision]), 4)
+        out["algorithmic_tflops_per_gpu"] = round(images_per_sec * flop / world / 1e12, 2)
+    if rank == 0 and not args.no_kernel_profile:
+        for r in reducers:  # the extra profiled step runs on rank 0 alone: no collectives
+            r.enabled = False
+        trainer.kl_hook = None
+        out["roofline"] = kernel_profile(trainer, args.precision)
+    if world > 1:
+        dist.barrier()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.size, args.channels)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

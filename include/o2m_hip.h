@@ -73,9 +73,20 @@ typedef struct {
   const float* bias;      /* [Co]    or NULL                     */
   const void* residual;   /* [B][Ho][Wo][Co] or NULL             */
   int32_t B, H, W, Ci, Co, KH, KW, pad, pad_mode, act, dtype;
-  int32_t reserved[5];
+  int32_t w_batch_stride; /* 0: one filter for all samples.  >0: sample b uses w + b*stride
+                             elements (pre-modulated per-sample filters, o2m_modulate_weights);
+                             requires Ho*Wo % 256 == 0 so no MFMA tile straddles samples */
+  int32_t reserved[4];
 } o2m_conv_desc;
 int o2m_conv2d_fwd(const o2m_conv_desc* d, void* stream);
+
+/* Per-sample pre-modulated filters for the forward modulated conv:
+ *   out[b][o][kh][kw][i] = (dtype) ( w32[o][kh][kw][i] * s[b][i] )
+ * i.e. layers.py:152-154 (weights * s) without the demodulation, which stays an epilogue
+ * scale.  w32 is fp32 [Co][KH*KW][Ci]; rounding to bf16 happens AFTER the style is folded in.
+ */
+int o2m_modulate_weights(const float* w32, const float* s, void* out, int32_t B, int32_t Co,
+                         int32_t KK, int32_t Ci, int32_t dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Weight gradient of the convolution above (the wgrad half of aten::convolution_backward
@@ -101,13 +112,16 @@ int o2m_conv2d_wgrad(const o2m_wgrad_desc* d, void* stream);
  * modulated conv and the bias need:
  *   sums[b,c,0] = sum_p gu ,  sums[b,c,1] = sum_p gu * (y - residual)
  * (second sum gives d loss / d out_scale = sums1 / out_scale for act in {none, relu}).
- * sums is fp32 [B][C][2], zeroed by the caller (accumulated with atomics).
+ * sums is fp32 [B][C][2], zeroed by the caller (accumulated with atomics).  If out_mul
+ * ([B][C] fp32) is given the STORED tensor is gu * out_mul[b,c] (the demodulation factor is
+ * folded here so that dgrad and wgrad of the modulated conv read it pre-scaled); the sums
+ * always use the unscaled gu.
  * Replaces the ReLU/LeakyReLU/Tanh backward and the bias reduction of
  * convolution_backward.  `y` is the forward OUTPUT (post-activation).
  */
-int o2m_act_bwd_reduce(const void* g, const void* y, const void* residual, void* gu,
-                       float* sums, int32_t B, int32_t P, int32_t C, int32_t act,
-                       int32_t dtype, void* stream);
+int o2m_act_bwd_reduce(const void* g, const void* y, const void* residual,
+                       const float* out_mul, void* gu, float* sums, int32_t B, int32_t P,
+                       int32_t C, int32_t act, int32_t dtype, void* stream);
 
 /* Backward of ReflectionPad2d fused with the style scale and the style-gradient dot:
  *   gfold = fold_reflect(gpad)             (pad == 0: identity)

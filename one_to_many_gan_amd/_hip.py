@@ -19,7 +19,7 @@ BF16, F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 PAD_ZERO, PAD_REFLECT = 0, 1
 RED_L1, RED_SQ, RED_MOM = 0, 1, 2
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -29,7 +29,7 @@ class ConvDesc(C.Structure):
                 ("bias", _vp), ("residual", _vp),
                 ("B", _i32), ("H", _i32), ("W", _i32), ("Ci", _i32), ("Co", _i32), ("KH", _i32),
                 ("KW", _i32), ("pad", _i32), ("pad_mode", _i32), ("act", _i32), ("dtype", _i32),
-                ("reserved", _i32 * 5)]
+                ("w_batch_stride", _i32), ("reserved", _i32 * 4)]
 
 
 class WgradDesc(C.Structure):
@@ -44,7 +44,8 @@ SIGNATURES = {
     "o2m_abi_version": (_i32, []),
     "o2m_conv2d_fwd": (_i32, [C.POINTER(ConvDesc), _vp]),
     "o2m_conv2d_wgrad": (_i32, [C.POINTER(WgradDesc), _vp]),
-    "o2m_act_bwd_reduce": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "o2m_act_bwd_reduce": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "o2m_modulate_weights": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "o2m_fold_scale_dot": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "o2m_instnorm_ws_floats": (C.c_size_t, [_i32, _i32, _i32]),
     "o2m_instnorm_stats": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp]),
@@ -61,6 +62,33 @@ SIGNATURES = {
 }
 
 _lib = None
+
+# bench.py sets this to a list to time every MFMA conv launch with a HIP-event pair on the
+# launch stream: entries are (kernel_name, algorithmic_flops, start_event, end_event).
+PROFILE = None
+
+
+def _igemm_name(dt, co, scaled):
+    t = "bf16" if dt == torch.bfloat16 else "f32x3"
+    tile = "128x128" if co > 64 else ("128x64" if co > 32 else "256x32")
+    return f"conv_igemm<{t},{tile},in_scale={int(scaled)}>"
+
+
+def _wgrad_name(dt, co):
+    t = "bf16" if dt == torch.bfloat16 else "f32x3"
+    tile = "128" if co > 64 else ("64" if co > 32 else "32")
+    return f"conv_wgrad<{t},co{tile}xk128>"
+
+
+def _timed(name, flops, tensor, launch):
+    if PROFILE is None:
+        return launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    st = torch.cuda.current_stream(tensor.device)
+    e0.record(st)
+    launch()
+    e1.record(st)
+    PROFILE.append((name, flops, e0, e1))
 
 
 def lib():
@@ -113,12 +141,16 @@ def check(err: int, what: str):
 # ------------------------------------------------------------------------------- wrappers
 
 
-def conv2d_fwd(x, w, y, *, in_scale=None, out_scale=None, bias=None, residual=None, pad, pad_mode, act):
+def conv2d_fwd(x, w, y, *, in_scale=None, out_scale=None, bias=None, residual=None, pad, pad_mode, act,
+               per_sample_w=False):
     B, H, W, Ci = x.shape
-    Co, KH, KW, _ = w.shape
+    Co, KH, KW, _ = w.shape[-4:]
+    stride = Co * KH * KW * Ci if per_sample_w else 0
     d = ConvDesc(ptr(x), ptr(w), ptr(y), ptr(in_scale), ptr(out_scale), ptr(bias), ptr(residual),
-                 B, H, W, Ci, Co, KH, KW, pad, pad_mode, act, dtype_code(x.dtype))
-    check(lib().o2m_conv2d_fwd(C.byref(d), _stream(x)), "o2m_conv2d_fwd")
+                 B, H, W, Ci, Co, KH, KW, pad, pad_mode, act, dtype_code(x.dtype), stride)
+    flops = 2.0 * y.shape[0] * y.shape[1] * y.shape[2] * Co * KH * KW * Ci
+    _timed(_igemm_name(x.dtype, Co, in_scale is not None), flops, x,
+           lambda: check(lib().o2m_conv2d_fwd(C.byref(d), _stream(x)), "o2m_conv2d_fwd"))
 
 
 def conv2d_wgrad(x, gy, dw, *, in_scale=None, gy_scale=None, pad, pad_mode, splits=0):
@@ -126,13 +158,22 @@ def conv2d_wgrad(x, gy, dw, *, in_scale=None, gy_scale=None, pad, pad_mode, spli
     Co, KH, KW, _ = dw.shape
     d = WgradDesc(ptr(x), ptr(gy), ptr(dw), ptr(in_scale), ptr(gy_scale), B, H, W, Ci, Co, KH, KW,
                   pad, pad_mode, dtype_code(x.dtype), splits)
-    check(lib().o2m_conv2d_wgrad(C.byref(d), _stream(x)), "o2m_conv2d_wgrad")
+    flops = 2.0 * gy.shape[0] * gy.shape[1] * gy.shape[2] * Co * KH * KW * Ci
+    _timed(_wgrad_name(x.dtype, Co), flops, x,
+           lambda: check(lib().o2m_conv2d_wgrad(C.byref(d), _stream(x)), "o2m_conv2d_wgrad"))
 
 
-def act_bwd_reduce(g, y, residual, gu, sums, act):
+def act_bwd_reduce(g, y, residual, out_mul, gu, sums, act):
     B, P, Cn = g.shape[0], g.shape[1] * g.shape[2], g.shape[3]
-    check(lib().o2m_act_bwd_reduce(ptr(g), ptr(y), ptr(residual), ptr(gu), ptr(sums), B, P, Cn, act,
-                                   dtype_code(g.dtype), _stream(g)), "o2m_act_bwd_reduce")
+    check(lib().o2m_act_bwd_reduce(ptr(g), ptr(y), ptr(residual), ptr(out_mul), ptr(gu), ptr(sums), B, P,
+                                   Cn, act, dtype_code(g.dtype), _stream(g)), "o2m_act_bwd_reduce")
+
+
+def modulate_weights(w32, s, out):
+    """out[b,o,kh,kw,i] = w32[o,kh,kw,i] * s[b,i] in the dtype of ``out``."""
+    Co, KH, KW, Ci = w32.shape
+    check(lib().o2m_modulate_weights(ptr(w32), ptr(s), ptr(out), s.shape[0], Co, KH * KW, Ci,
+                                     dtype_code(out.dtype), _stream(out)), "o2m_modulate_weights")
 
 
 def fold_scale_dot(gpad, x, scale, gx, dots, pad):

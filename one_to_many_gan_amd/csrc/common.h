@@ -92,6 +92,16 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (bid % 8 labels
+// the blocks that share an L2), so consecutive LOGICAL tiles -- which share operand panels --
+// are handed to one XCD: logical = (chunk of that XCD) + position inside it.  Bijective for
+// any grid size.  Speed only; nothing depends on the placement.
+__device__ __forceinline__ int xcd_tile_order(int bid, int n) {
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int q = n >> 3, r = n & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 #define O2M_LAUNCH_CHECK()                        \
   do {                                            \
     hipError_t e__ = hipGetLastError();           \

@@ -3,14 +3,19 @@
 //   GEMM view:  M = B*Ho*Wo (output pixels), N = Co, K = KH*KW*Ci (ci fastest).
 //   A[m][k] is gathered on the fly from the NHWC input (im2col never materialised);
 //   zero or reflect padding is index arithmetic in the loader; the per-(b,ci) style scale
-//   of the modulated conv is applied while the tile sits in registers, before it is
-//   written to LDS.  B[n][k] is the filter, stored [Co][KH][KW][Ci] so both operands are
-//   K-contiguous and share one fragment path.
+//   of the modulated conv (fallback path) is applied while the tile sits in registers.
+//   B[n][k] is the filter, stored [Co][KH][KW][Ci] so both operands are K-contiguous and
+//   share one fragment path.
 //
-//   Block = 256 threads = 4 waves; tile BM x BN x 64; each wave owns a grid of 32x32 MFMA
-//   tiles (v_mfma_f32_32x32x16_bf16, fp32 accumulate).  Global -> registers -> LDS staging
-//   (16 B per lane, issue-early / write-late, two LDS stages), XOR-swizzled 16-B slots so
-//   the ds_read_b128 fragment reads are bank-conflict free.
+//   Tile BM x BN x 64, 4 or 8 waves; each wave owns a grid of 32x32 MFMA tiles
+//   (v_mfma_f32_32x32x16_bf16, fp32 accumulate).  Global -> registers -> LDS staging (16 B per
+//   lane, issue-early / write-late, two LDS stages), XOR-swizzled 16-B slots: the
+//   ds_read_b128 fragment reads are bank-conflict free (SQ_LDS_BANK_CONFLICT = 0).
+//
+//   The reduction is walked tap-outer / channel-inner: the gather address of a pixel row
+//   (bounds test or mirror) is computed once per filter tap and then advanced by 64
+//   channels with ONE add per stage -- the first version recomputed it every stage and was
+//   VALU-issue-bound at 16 VALU per MFMA (profiles/r01_b_pmc_igemm_before.txt).
 //
 //   dtype O2M_F32 ("parity mode"): operands are split hi + lo into two bf16 tiles while
 //   staging and every product runs as hi*hi + hi*lo + lo*hi on the bf16 MFMA: ~2^-16
@@ -20,7 +25,6 @@
 namespace {
 
 constexpr int BK = 64;  // reduction elements per stage (one 128-B LDS row of bf16)
-constexpr int NT = 256;
 
 // Byte offset of 16-B slot (row, chunk) in a [rows][64] bf16 tile.  Two 128-B rows share a
 // 256-B bank row; XOR with (row>>1)&15 spreads each ds_read_b128 lane group (same chunk,
@@ -33,17 +37,20 @@ template <typename T> struct Stg;  // staged registers for 8 consecutive reducti
 template <> struct Stg<unsigned short> { u32x4 v; };
 template <> struct Stg<float> { f32x4 a, b; };
 
-__device__ __forceinline__ void stg_zero(Stg<unsigned short>& s) { s.v = u32x4{0, 0, 0, 0}; }
-__device__ __forceinline__ void stg_zero(Stg<float>& s) {
-  s.a = f32x4{0.f, 0.f, 0.f, 0.f};
-  s.b = f32x4{0.f, 0.f, 0.f, 0.f};
+// Raw buffer descriptor over a whole tensor: a load whose byte offset is >= the size
+// returns zeros, which is how padding taps / rows outside the problem are zero-filled
+// without branches (invalid rows carry the offset OOB_OFF).
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+constexpr unsigned OOB_OFF = 0x80000000u;  // tensors are limited to < 2 GiB (checked on the host)
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
 }
-__device__ __forceinline__ void stg_load(Stg<unsigned short>& s, const unsigned short* p) {
-  s.v = *reinterpret_cast<const u32x4*>(p);
+__device__ __forceinline__ void stg_load(Stg<unsigned short>& s, rsrc_t r, unsigned byte_off) {
+  s.v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
 }
-__device__ __forceinline__ void stg_load(Stg<float>& s, const float* p) {
-  s.a = *reinterpret_cast<const f32x4*>(p);
-  s.b = *reinterpret_cast<const f32x4*>(p + 4);
+__device__ __forceinline__ void stg_load(Stg<float>& s, rsrc_t r, unsigned byte_off) {
+  s.a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
+  s.b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off + 16, 0, 0));
 }
 __device__ __forceinline__ void stg_unpack(const Stg<unsigned short>& s, float (&f)[8]) {
 #pragma unroll
@@ -90,22 +97,25 @@ __device__ __forceinline__ void stg_to_lds(const Stg<T>& s, const f32x4 (&sc)[2]
   }
 }
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool IN_SCALE>
-__global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(const o2m_conv_desc d) {
+// WIDE: Ci % 64 == 0, so one 64-element stage lies inside ONE filter tap (tap-outer walk).
+// !WIDE: small Ci (image stems, Ci = 8..32): every 16-B chunk decodes its own tap.
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool IN_SCALE, bool WIDE>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(const o2m_conv_desc d) {
+  constexpr int NT = 64 * WAVES_M * WAVES_N;
   constexpr bool F32 = sizeof(T) == 4;
   constexpr int NPLANE = F32 ? 2 : 1;  // hi (+ lo)
   constexpr int NSTAGE = F32 ? 1 : 2;
-  constexpr int RA = BM / 32, RB = BN / 32;  // 16-B loads per thread per stage
+  constexpr int RSTEP = NT / 8;  // rows covered by one pass of the block's threads
+  constexpr int RA = BM / RSTEP, RB = (BN + RSTEP - 1) / RSTEP;
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
   constexpr int STAGE_BYTES = NPLANE * (A_BYTES + B_BYTES);
-  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+  static_assert(BM % RSTEP == 0 && WM % 32 == 0 && WN % 32 == 0, "tile shape");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  const T* __restrict__ X = static_cast<const T*>(d.x);
-  const T* __restrict__ Wt = static_cast<const T*>(d.w);
+  constexpr int ES = sizeof(T);  // element size in bytes
   const int H = d.H, W = d.W, Ci = d.Ci, Co = d.Co, KH = d.KH, KW = d.KW, pad = d.pad;
   const int Ho = H + 2 * pad - KH + 1, Wo = W + 2 * pad - KW + 1;
   const int HoWo = Ho * Wo;
@@ -115,86 +125,144 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(const o2m_conv_desc d
   const bool reflect = d.pad_mode == O2M_PAD_REFLECT;
 
   const int tiles_n = (Co + BN - 1) / BN;
-  const int m0 = (blockIdx.x / tiles_n) * BM;
-  const int n0 = (blockIdx.x % tiles_n) * BN;
+  const int tile = xcd_tile_order(blockIdx.x, gridDim.x);
+  const int m0 = (tile / tiles_n) * BM;
+  const int n0 = (tile % tiles_n) * BN;
+
+  // sample of the tile's first pixel; uniform over the tile when it does not straddle samples
+  const int b_first = m0 / HoWo;
+  const bool b_uniform = (min(m0 + BM, M) - 1) / HoWo == b_first;
+  const rsrc_t xr = make_rsrc(d.x, (unsigned)((size_t)d.B * H * W * Ci * ES));
+  // per-sample filters (host guarantees the tile does not straddle samples)
+  const rsrc_t wr = make_rsrc(static_cast<const char*>(d.w) + (size_t)b_first * d.w_batch_stride * ES,
+                              (unsigned)((size_t)Co * K * ES));
 
   const int tid = threadIdx.x;
   const int cc = tid & 7;   // 16-B chunk (8 reduction elements) inside the 64-wide stage
-  const int r0 = tid >> 3;  // 0..31
+  const int r0 = tid >> 3;  // 0 .. RSTEP-1
 
   // ---- per-thread row bookkeeping for the A gather ---------------------------------
-  int rb[RA], roy[RA], rox[RA];
+  // pix[j] = linear pixel index (b*H + oy)*W + ox of output pixel (b,oy,ox) taken in the INPUT
+  // grid (-1: row outside M); ryx[j] = oy << 16 | ox.
+  int pix[RA], ryx[RA];
 #pragma unroll
   for (int j = 0; j < RA; ++j) {
-    int m = m0 + r0 + 32 * j;
+    const int m = m0 + r0 + RSTEP * j;
     if (m < M) {
-      int b = m / HoWo, rem = m - b * HoWo;
-      rb[j] = b;
-      roy[j] = rem / Wo;
-      rox[j] = rem - roy[j] * Wo;
+      const int b = m / HoWo, rem = m - b * HoWo;
+      const int oy = rem / Wo, ox = rem - oy * Wo;
+      pix[j] = (b * H + oy) * W + ox;
+      ryx[j] = (oy << 16) | ox;
     } else {
-      rb[j] = -1; roy[j] = 0; rox[j] = 0;
+      pix[j] = -1;
+      ryx[j] = 0;
     }
   }
+  // LDS write offset of this thread's first row; row r0 + RSTEP*j adds j*RSTEP*128 bytes
+  // (RSTEP is a multiple of 32, so the XOR term of tile_off is unchanged)
+  const int woff0 = tile_off(r0, cc);
+  // filter rows of this thread: element offset of row 0 and a validity bit per row
+  const unsigned wbase0 = (unsigned)((n0 + r0) * K + cc * 8) * ES;  // bytes
+  unsigned wvalid = 0;
+#pragma unroll
+  for (int j = 0; j < RB; ++j)
+    if (r0 + RSTEP * j < BN && n0 + r0 + RSTEP * j < Co) wvalid |= 1u << j;
 
   Stg<T> sa[RA], sb[RB];
   f32x4 sca[IN_SCALE ? RA : 1][2];
 
-  auto load_tiles = [&](int kt) {
-    const int k = kt * BK + cc * 8;
-    const bool kv = k < K;
-    const int tap = k / Ci, ci0 = k - tap * Ci;
-    const int kh = tap / KW, kw = tap - kh * KW;
+  // tap-outer walk state (WIDE): element offset of (row, tap), or -1 when the tap falls in
+  // the zero padding / the row is outside M
+  unsigned aoff[RA];  // byte offsets
+  int cur_tap = -1;   // uniform
+
+  auto set_tap = [&](int tap) {
+    const int dy = tap / KW - pad, dx = tap - (tap / KW) * KW - pad;  // scalar
 #pragma unroll
     for (int j = 0; j < RA; ++j) {
-      int iy = roy[j] + kh - pad, ix = rox[j] + kw - pad;
-      bool ok = kv && rb[j] >= 0;
+      const int oy = ryx[j] >> 16, ox = ryx[j] & 0xffff;
+      int iy = oy + dy, ix = ox + dx;
+      bool ok = pix[j] >= 0;
       if (reflect) {
         iy = iy < 0 ? -iy : (iy >= H ? 2 * H - 2 - iy : iy);
         ix = ix < 0 ? -ix : (ix >= W ? 2 * W - 2 - ix : ix);
       } else {
         ok = ok && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
       }
-      if (ok) {
-        size_t off = ((size_t)(rb[j] * H + iy) * W + ix) * Ci + ci0;
-        stg_load(sa[j], X + off);
-      } else {
-        stg_zero(sa[j]);
-      }
-      if constexpr (IN_SCALE) {
-        if (ok) {
-          const float* sp = d.in_scale + (size_t)rb[j] * Ci + ci0;
-          sca[j][0] = *reinterpret_cast<const f32x4*>(sp);
-          sca[j][1] = *reinterpret_cast<const f32x4*>(sp + 4);
-        } else {
-          sca[j][0] = sca[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      aoff[j] = ok ? (unsigned)((pix[j] + (iy - oy) * W + (ix - ox)) * Ci + cc * 8) * ES : OOB_OFF;
+    }
+  };
+
+  auto load_tiles = [&](int kt) {
+    if constexpr (WIDE) {
+      const int k0 = kt * BK;           // scalar
+      const int tap = k0 / Ci;          // scalar
+      const int cbase = k0 - tap * Ci;  // scalar
+      if (tap != cur_tap) { set_tap(tap); cur_tap = tap; }
+#pragma unroll
+      for (int j = 0; j < RA; ++j) {
+        stg_load(sa[j], xr, aoff[j] + (unsigned)cbase * ES);
+        if constexpr (IN_SCALE) {
+          if (aoff[j] != OOB_OFF) {
+            const float* sp = d.in_scale + (size_t)((m0 + r0 + RSTEP * j) / HoWo) * Ci + cbase + cc * 8;
+            sca[j][0] = *reinterpret_cast<const f32x4*>(sp);
+            sca[j][1] = *reinterpret_cast<const f32x4*>(sp + 4);
+          } else {
+            sca[j][0] = sca[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
         }
       }
-    }
 #pragma unroll
-    for (int j = 0; j < RB; ++j) {
-      int n = n0 + r0 + 32 * j;
-      if (kv && n < Co) stg_load(sb[j], Wt + (size_t)n * K + k);
-      else stg_zero(sb[j]);
+      for (int j = 0; j < RB; ++j)
+        stg_load(sb[j], wr, (wvalid >> j & 1) ? wbase0 + (unsigned)(j * RSTEP * K + k0) * ES : OOB_OFF);
+    } else {
+      const int k = kt * BK + cc * 8;
+      const bool kv = k < K;
+      const int tap = k / Ci, ci0 = k - tap * Ci;
+      const int dy = tap / KW - pad, dx = tap - (tap / KW) * KW - pad;
+#pragma unroll
+      for (int j = 0; j < RA; ++j) {
+        const int oy = ryx[j] >> 16, ox = ryx[j] & 0xffff;
+        int iy = oy + dy, ix = ox + dx;
+        bool ok = kv && pix[j] >= 0;
+        if (reflect) {
+          iy = iy < 0 ? -iy : (iy >= H ? 2 * H - 2 - iy : iy);
+          ix = ix < 0 ? -ix : (ix >= W ? 2 * W - 2 - ix : ix);
+        } else {
+          ok = ok && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        }
+        stg_load(sa[j], xr, ok ? (unsigned)((pix[j] + (iy - oy) * W + (ix - ox)) * Ci + ci0) * ES : OOB_OFF);
+        if constexpr (IN_SCALE) {
+          if (ok) {
+            const float* sp = d.in_scale + (size_t)((m0 + r0 + RSTEP * j) / HoWo) * Ci + ci0;
+            sca[j][0] = *reinterpret_cast<const f32x4*>(sp);
+            sca[j][1] = *reinterpret_cast<const f32x4*>(sp + 4);
+          } else {
+            sca[j][0] = sca[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < RB; ++j)
+        stg_load(sb[j], wr, (kv && (wvalid >> j & 1)) ? wbase0 + (unsigned)(j * RSTEP * K + kt * BK) * ES : OOB_OFF);
     }
   };
 
   auto store_tiles = [&](int stage) {
     char* base = smem + stage * STAGE_BYTES;
     char* a_hi = base;
-    char* a_lo = base + A_BYTES;                  // only used when F32
+    char* a_lo = base + A_BYTES;  // only used when F32
     char* b_hi = base + NPLANE * A_BYTES;
     char* b_lo = b_hi + B_BYTES;
     const f32x4 none[2] = {};
 #pragma unroll
     for (int j = 0; j < RA; ++j) {
-      if constexpr (IN_SCALE)
-        stg_to_lds<T, true>(sa[j], sca[j], a_hi, a_lo, tile_off(r0 + 32 * j, cc));
-      else
-        stg_to_lds<T, false>(sa[j], none, a_hi, a_lo, tile_off(r0 + 32 * j, cc));
+      if constexpr (IN_SCALE) stg_to_lds<T, true>(sa[j], sca[j], a_hi, a_lo, woff0 + j * RSTEP * 128);
+      else stg_to_lds<T, false>(sa[j], none, a_hi, a_lo, woff0 + j * RSTEP * 128);
     }
 #pragma unroll
-    for (int j = 0; j < RB; ++j) stg_to_lds<T, false>(sb[j], none, b_hi, b_lo, tile_off(r0 + 32 * j, cc));
+    for (int j = 0; j < RB; ++j)
+      if (r0 + RSTEP * j < BN) stg_to_lds<T, false>(sb[j], none, b_hi, b_lo, woff0 + j * RSTEP * 128);
   };
 
   // ---- accumulators ------------------------------------------------------------------
@@ -209,6 +277,14 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(const o2m_conv_desc d
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // fragment read offsets: tile_off(row, ks*2+lh) = tile_off(row, lh) ^ (ks << 5): the chunk
+  // index only enters the XOR-ed 16-B slot field
+  int fa[TM], fb[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) fa[i] = tile_off(wm + i * 32 + lr, lh);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) fb[j] = tile_off(wn + j * 32 + lr, lh);
+
   auto compute = [&](int stage) {
     const char* base = smem + stage * STAGE_BYTES;
     const char* a_hi = base;
@@ -217,17 +293,16 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(const o2m_conv_desc d
     const char* b_lo = b_hi + B_BYTES;
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
-      const int chunk = ks * 2 + lh;
       bf16x8 ah[TM], bh[TN], al[F32 ? TM : 1], bl[F32 ? TN : 1];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        int off = tile_off(wm + i * 32 + lr, chunk);
+        const int off = fa[i] ^ (ks << 5);
         ah[i] = *reinterpret_cast<const bf16x8*>(a_hi + off);
         if constexpr (F32) al[i] = *reinterpret_cast<const bf16x8*>(a_lo + off);
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        int off = tile_off(wn + j * 32 + lr, chunk);
+        const int off = fb[j] ^ (ks << 5);
         bh[j] = *reinterpret_cast<const bf16x8*>(b_hi + off);
         if constexpr (F32) bl[j] = *reinterpret_cast<const bf16x8*>(b_lo + off);
       }
@@ -241,6 +316,9 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(const o2m_conv_desc d
           }
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
+      // keep the fragment registers of ONE k-step live at a time (the big tiles sit at the
+      // 256-VGPR limit; the second wave of the SIMD covers the ds_read latency)
+      if constexpr (TM * TN >= 8) __builtin_amdgcn_sched_barrier(0);
     }
   };
 
@@ -258,55 +336,123 @@ __global__ __launch_bounds__(NT, 2) void conv_igemm_kernel(const o2m_conv_desc d
     __syncthreads();
   }
 
-  // ---- epilogue: C[row = pixel][col = channel]; lane owns one channel, 16 pixels -----
+  // ---- epilogue -----------------------------------------------------------------------
+  // The MFMA leaves each lane with ONE channel and 16 pixels: stored directly that is 64
+  // two-byte stores per lane.  Instead the raw fp32 tile goes through LDS (conflict-free
+  // ds_write_b32: 32 lanes = 32 consecutive channels of one pixel) and leaves as whole
+  // 16-B / 32-B channel vectors of a pixel row, coalesced; demodulation scale, bias,
+  // activation and residual are applied on the way out.  One pass per wave-row.
+  constexpr int CSTR = BN + 4;  // floats per staged row (+16 B: rows start on different banks)
+  float* csm = reinterpret_cast<float*>(smem);
   T* __restrict__ Y = static_cast<T*>(d.y);
   const T* __restrict__ R = static_cast<const T*>(d.residual);
+  constexpr int VPR = BN / 8;  // 8-channel vectors per row
   const int act = d.act;
+#pragma unroll 1
+  for (int pass = 0; pass < WAVES_M; ++pass) {
+    if (pass == wave / WAVES_N) {
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + wn + j * 32 + lr;
-    if (n >= Co) continue;
-    const float bias = d.bias ? d.bias[n] : 0.f;
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (m >= M) continue;
-        float v = acc[i][j][r];
-        if (d.out_scale) v *= d.out_scale[(size_t)(m / HoWo) * Co + n];
-        v = act_fwd(v + bias, act);
-        const size_t o = (size_t)m * Co + n;
-        if (R) v += Elem<T>::ld(R + o);
-        Elem<T>::st(Y + o, v);
-      }
+          for (int r = 0; r < 16; ++r)
+            csm[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * CSTR + wn + j * 32 + lr] = acc[i][j][r];
     }
+    __syncthreads();
+    const int mbase = m0 + pass * WM;
+#pragma unroll 1
+    for (int v = tid; v < WM * VPR; v += NT) {
+      const int row = v / VPR, c8 = v - row * VPR;
+      const int m = mbase + row, n = n0 + c8 * 8;
+      if (m >= M || n >= Co) continue;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(csm + row * CSTR + c8 * 8);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(csm + row * CSTR + c8 * 8 + 4);
+      float o[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+      if (d.out_scale) {
+        const float* sp = d.out_scale + (size_t)(b_uniform ? b_first : m / HoWo) * Co + n;
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { o[q] *= s0[q]; o[4 + q] *= s1[q]; }
+      }
+      if (d.bias) {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(d.bias + n), b1 = *reinterpret_cast<const f32x4*>(d.bias + n + 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { o[q] += b0[q]; o[4 + q] += b1[q]; }
+      }
+      if (act != O2M_ACT_NONE) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] = act_fwd(o[q], act);
+      }
+      const size_t off = (size_t)m * Co + n;
+      if (R) {
+        float rv[8];
+        load8(R + off, rv);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] += rv[q];
+      }
+      store8(Y + off, o);
+    }
+    if (pass + 1 < WAVES_M) __syncthreads();
   }
 }
 
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
-int launch_cfg(const o2m_conv_desc& d, hipStream_t s) {
+constexpr int lds_bytes() {
   constexpr bool F32 = sizeof(T) == 4;
-  constexpr int lds = (F32 ? 2 : 1) * (F32 ? 1 : 2) * (BM + BN) * BK * 2;
+  constexpr int lds_main = (F32 ? 2 : 1) * (F32 ? 1 : 2) * (BM + BN) * BK * 2;
+  constexpr int lds_epi = (BM / WAVES_M) * (BN + 4) * 4;
+  return lds_main > lds_epi ? lds_main : lds_epi;
+}
+
+template <int BM, int BN>
+long tiles_for(const o2m_conv_desc& d) {
   const int Ho = d.H + 2 * d.pad - d.KH + 1, Wo = d.W + 2 * d.pad - d.KW + 1;
   const long M = (long)d.B * Ho * Wo;
-  const long tiles = ((M + BM - 1) / BM) * ((d.Co + BN - 1) / BN);
+  return ((M + BM - 1) / BM) * ((d.Co + BN - 1) / BN);
+}
+
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
+int launch_cfg(const o2m_conv_desc& d, hipStream_t s) {
+  constexpr int lds = lds_bytes<T, BM, BN, WAVES_M, WAVES_N>();
+  constexpr int NT = 64 * WAVES_M * WAVES_N;
+  const long tiles = tiles_for<BM, BN>(d);
   if (tiles <= 0 || tiles > 0x7fffffffL) return O2M_ERR_BAD_ARG;
   auto go = [&](auto kern) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(NT), lds, s, d);
   };
-  if (d.in_scale) go(conv_igemm_kernel<T, BM, BN, WAVES_M, WAVES_N, true>);
-  else go(conv_igemm_kernel<T, BM, BN, WAVES_M, WAVES_N, false>);
+  const bool wide = d.Ci % BK == 0;
+  if (d.in_scale) {
+    if (wide) go(conv_igemm_kernel<T, BM, BN, WAVES_M, WAVES_N, true, true>);
+    else go(conv_igemm_kernel<T, BM, BN, WAVES_M, WAVES_N, true, false>);
+  } else {
+    if (wide) go(conv_igemm_kernel<T, BM, BN, WAVES_M, WAVES_N, false, true>);
+    else go(conv_igemm_kernel<T, BM, BN, WAVES_M, WAVES_N, false, false>);
+  }
   O2M_LAUNCH_CHECK();
   return 0;
 }
 
+constexpr long kFillBlocks = 256;  // one block per CU
+
 template <typename T>
 int launch_dtype(const o2m_conv_desc& d, hipStream_t s) {
-  if (d.Co > 64) return launch_cfg<T, 128, 128, 2, 2>(d, s);
-  if (d.Co > 32) return launch_cfg<T, 128, 64, 2, 2>(d, s);
+  // big 8-wave tiles when they still give every CU a block; otherwise the 4-wave 128-wide
+  // tiles (small-M layers of the discriminator) so the chip stays filled
+  if (d.Co > 128) {
+    if (tiles_for<256, 256>(d) >= kFillBlocks) return launch_cfg<T, 256, 256, 2, 4>(d, s);
+    return launch_cfg<T, 128, 128, 2, 2>(d, s);
+  }
+  if (d.Co > 64) {
+    if (tiles_for<256, 128>(d) >= kFillBlocks) return launch_cfg<T, 256, 128, 4, 2>(d, s);
+    return launch_cfg<T, 128, 128, 2, 2>(d, s);
+  }
+  if (d.Co > 32) {
+    if (tiles_for<256, 64>(d) >= kFillBlocks) return launch_cfg<T, 256, 64, 4, 2>(d, s);
+    return launch_cfg<T, 128, 64, 2, 2>(d, s);
+  }
   return launch_cfg<T, 256, 32, 4, 1>(d, s);
 }
 
@@ -319,7 +465,15 @@ extern "C" int o2m_conv2d_fwd(const o2m_conv_desc* d, void* stream) {
   if (d->H + 2 * d->pad < d->KH || d->W + 2 * d->pad < d->KW) return O2M_ERR_BAD_ARG;
   if (d->pad_mode == O2M_PAD_REFLECT && (d->pad >= d->H || d->pad >= d->W)) return O2M_ERR_BAD_ARG;
   if (d->pad_mode != O2M_PAD_ZERO && d->pad_mode != O2M_PAD_REFLECT) return O2M_ERR_BAD_ARG;
-  if ((long)d->B * d->H * d->W * (long)d->Ci > 0x7fffffffL) return O2M_ERR_UNSUPPORTED;
+  const long esz = d->dtype == O2M_F32 ? 4 : 2;
+  // buffer descriptors address < 2 GiB per tensor (offset 0x80000000 marks "out of range")
+  if ((long)d->B * d->H * d->W * (long)d->Ci * esz > 0x7fffffffL) return O2M_ERR_UNSUPPORTED;
+  if (d->w_batch_stride < 0) return O2M_ERR_BAD_ARG;
+  if ((long)d->Co * d->KH * d->KW * (long)d->Ci * esz > 0x7fffffffL) return O2M_ERR_UNSUPPORTED;
+  if (d->w_batch_stride > 0) {
+    const long howo = (long)(d->H + 2 * d->pad - d->KH + 1) * (d->W + 2 * d->pad - d->KW + 1);
+    if (howo % 256 != 0 || d->in_scale) return O2M_ERR_BAD_ARG;
+  }
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (d->dtype == O2M_BF16) return launch_dtype<unsigned short>(*d, s);
   if (d->dtype == O2M_F32) return launch_dtype<float>(*d, s);

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const o2m_wgrad_desc 
   const int K = KH * KW * Ci;
   const bool reflect = d.pad_mode == O2M_PAD_REFLECT;
 
-  int bid = blockIdx.x;
+  int bid = xcd_tile_order(blockIdx.x, gridDim.x);  // a split's tiles share x / gy: one XCD
   const int tk = bid % tiles_k; bid /= tiles_k;
   const int tco = bid % tiles_co; bid /= tiles_co;
   const int split = bid;

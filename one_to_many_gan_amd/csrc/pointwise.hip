@@ -48,15 +48,18 @@ __device__ __forceinline__ void lanes_reduce(float (&v)[NV], int cv, int pl, int
 // ---- act backward + per-(b,c) sums --------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(NT) void act_bwd_reduce_kernel(const T* g, const T* y, const T* res,
-                                                            T* gu, float* sums, int P, int C,
-                                                            int act, ChanGeom gm) {
+                                                            const float* out_mul, T* gu,
+                                                            float* sums, int P, int C, int act,
+                                                            ChanGeom gm) {
   extern __shared__ float sm[];
   const int b = blockIdx.y, ch = blockIdx.x;
   const int cv = threadIdx.x % gm.CV, pl = threadIdx.x / gm.CV;
   const int pe = min(P, (ch + 1) * gm.chunk);
-  float acc[16];
+  float acc[16], mul[8];
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) mul[i] = out_mul ? out_mul[(size_t)b * C + cv * 8 + i] : 1.f;
   if (pl < gm.PL) {
     for (int p = ch * gm.chunk + pl; p < pe; p += gm.PL) {
       const size_t o = ((size_t)b * P + p) * C + cv * 8;
@@ -68,7 +71,7 @@ __global__ __launch_bounds__(NT) void act_bwd_reduce_kernel(const T* g, const T*
       for (int i = 0; i < 8; ++i) {
         float u = res ? yv[i] - rv[i] : yv[i];
         float d = gv[i] * act_bwd_from_out(u, act);
-        ov[i] = d;
+        ov[i] = d * mul[i];
         acc[i] += d;
         acc[8 + i] += d * u;
       }
@@ -380,6 +383,23 @@ __global__ __launch_bounds__(NT) void reduce_bwd_kernel(const T* a, const T* b, 
   }
 }
 
+// ---- per-sample modulated filters ---------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(NT) void modulate_weights_kernel(const float* w32, const float* s, T* out,
+                                                              long per, int Ci) {
+  const int b = blockIdx.y;
+  const int CV = Ci / 8;
+  for (long v = (long)blockIdx.x * NT + threadIdx.x; v < per; v += (long)gridDim.x * NT) {
+    const int cv = (int)(v % CV);
+    float w[8], sv[8];
+    load8(w32 + (size_t)v * 8, w);
+    load8(s + (size_t)b * Ci + cv * 8, sv);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w[i] *= sv[i];
+    store8(out + ((size_t)b * per + v) * 8, w);
+  }
+}
+
 // ---- fused Adam ------------------------------------------------------------------------------
 __global__ __launch_bounds__(NT) void adam_kernel(float* p, const float* g, float* m, float* v,
                                                   const float* step, long n, float lr, float b1,
@@ -414,18 +434,30 @@ inline unsigned grid_for(long n, int per_block = NT) {
 
 extern "C" {
 
-int o2m_abi_version(void) { return 1; }
+int o2m_abi_version(void) { return 2; }
 
-int o2m_act_bwd_reduce(const void* g, const void* y, const void* residual, void* gu, float* sums,
-                       int32_t B, int32_t P, int32_t C, int32_t act, int32_t dtype, void* stream) {
+int o2m_modulate_weights(const float* w32, const float* s, void* out, int32_t B, int32_t Co,
+                         int32_t KK, int32_t Ci, int32_t dtype, void* stream) {
+  if (!w32 || !s || !out || B <= 0 || Co <= 0 || KK <= 0 || Ci <= 0 || (Ci & 7)) return O2M_ERR_BAD_ARG;
+  const long per = (long)Co * KK * (Ci / 8);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(modulate_weights_kernel<T>, dim3(grid_for(per), B), dim3(NT), 0, st,
+                                       w32, s, (T*)out, per, Ci));
+  O2M_LAUNCH_CHECK();
+  return 0;
+}
+
+int o2m_act_bwd_reduce(const void* g, const void* y, const void* residual, const float* out_mul,
+                       void* gu, float* sums, int32_t B, int32_t P, int32_t C, int32_t act,
+                       int32_t dtype, void* stream) {
   if (!g || !y || !gu || !sums || B <= 0 || P <= 0 || C <= 0 || (C & 7) || C > 8 * NT)
     return O2M_ERR_BAD_ARG;
   ChanGeom gm = chan_geom(B, P, C);
   const size_t lds = (size_t)gm.PL * gm.CV * 16 * sizeof(float);
   hipStream_t s = static_cast<hipStream_t>(stream);
   DISPATCH_T(dtype, hipLaunchKernelGGL(act_bwd_reduce_kernel<T>, dim3(gm.nchunks, B), dim3(NT), lds, s,
-                                       (const T*)g, (const T*)y, (const T*)residual, (T*)gu, sums, P,
-                                       C, act, gm));
+                                       (const T*)g, (const T*)y, (const T*)residual, out_mul, (T*)gu,
+                                       sums, P, C, act, gm));
   O2M_LAUNCH_CHECK();
   return 0;
 }

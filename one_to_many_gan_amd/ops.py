@@ -131,7 +131,7 @@ class PreparedWeight:
                 w_f = full.to(compute_dtype()).contiguous()
                 w_d = full.flip(1, 2).permute(3, 1, 2, 0).to(compute_dtype()).contiguous()
                 q = full.square().sum(dim=(1, 2)).contiguous() if self.need_q else None
-            self._val = (w_f, w_d, q)
+            self._val = (w_f, w_d, q, full if self.need_q else None)
             self._key = key
         return self._val
 
@@ -153,7 +153,7 @@ class _ConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, style, residual, prep, pad, pad_mode, act, demodulate, eps):
-        w_f, w_d, q = prep.get()
+        w_f, w_d, q, w32 = prep.get()
         B, Hh, Ww, cip = x.shape
         if cip != prep.cip:
             raise RuntimeError(f"conv input has {cip} channels, layer expects {prep.cip} (padded)")
@@ -169,8 +169,16 @@ class _ConvFn(torch.autograd.Function):
             bias_p = torch.zeros(prep.cop, dtype=torch.float32, device=x.device)
             bias_p[: prep.co] = bias.detach().float()
         y = torch.empty((B, ho, wo, prep.cop), dtype=x.dtype, device=x.device)
-        H.conv2d_fwd(x, w_f, y, in_scale=s, out_scale=d, bias=bias_p, residual=residual,
-                     pad=pad, pad_mode=pad_mode, act=act)
+        if s is not None and (ho * wo) % 256 == 0:
+            # style folded into per-sample filters (rounded after folding): the A-operand
+            # loader stays a plain copy, like the unmodulated conv
+            w_b = torch.empty((B, *w_f.shape), dtype=x.dtype, device=x.device)
+            H.modulate_weights(w32, s, w_b)
+            H.conv2d_fwd(x, w_b, y, out_scale=d, bias=bias_p, residual=residual, pad=pad,
+                         pad_mode=pad_mode, act=act, per_sample_w=True)
+        else:
+            H.conv2d_fwd(x, w_f, y, in_scale=s, out_scale=d, bias=bias_p, residual=residual,
+                         pad=pad, pad_mode=pad_mode, act=act)
         ctx.prep, ctx.pad, ctx.pad_mode, ctx.act = prep, pad, pad_mode, act
         ctx.has_bias, ctx.has_res = bias is not None, residual is not None
         ctx.save_for_backward(x, y, residual, s, d, weight, bias_p)
@@ -180,7 +188,7 @@ class _ConvFn(torch.autograd.Function):
     def backward(ctx, g):
         x, y, residual, s, d, weight, bias_p = ctx.saved_tensors
         prep, pad, pad_mode, act = ctx.prep, ctx.pad, ctx.pad_mode, ctx.act
-        w_f, w_d, q = prep.get()
+        w_f, w_d, q, _ = prep.get()
         g = g.contiguous()
         B, Hh, Ww, cip = x.shape
         need_x, need_w, need_b, need_s = ctx.needs_input_grad[0:4]
@@ -190,7 +198,8 @@ class _ConvFn(torch.autograd.Function):
         if act != H.ACT_NONE or d is not None:
             gu = torch.empty_like(g)
             sums = torch.zeros((B, prep.cop, 2), dtype=torch.float32, device=g.device)
-            H.act_bwd_reduce(g, y, residual, gu, sums, act)  # u = y - residual = act(pre)
+            # u = y - residual = act(pre); the stored tensor is gu * d (demodulation folded in)
+            H.act_bwd_reduce(g, y, residual, d, gu, sums, act)
         else:
             gu = g
 
@@ -205,7 +214,7 @@ class _ConvFn(torch.autograd.Function):
             hp = Hh + (2 * pad if pad_mode == H.PAD_REFLECT else 0)
             wp = Ww + (2 * pad if pad_mode == H.PAD_REFLECT else 0)
             gxp = torch.empty((B, hp, wp, cip), dtype=g.dtype, device=g.device)
-            H.conv2d_fwd(gu, w_d, gxp, in_scale=d, pad=kpad, pad_mode=H.PAD_ZERO, act=H.ACT_NONE)
+            H.conv2d_fwd(gu, w_d, gxp, pad=kpad, pad_mode=H.PAD_ZERO, act=H.ACT_NONE)
             if s is not None or pad_mode == H.PAD_REFLECT:
                 g_x = torch.empty_like(x)
                 if s is not None:
@@ -218,7 +227,7 @@ class _ConvFn(torch.autograd.Function):
         g_w = e = None
         if need_w:
             dw = torch.zeros((prep.cop, prep.kh, prep.kw, cip), dtype=torch.float32, device=g.device)
-            H.conv2d_wgrad(x, gu, dw, in_scale=s, gy_scale=d, pad=pad, pad_mode=pad_mode)
+            H.conv2d_wgrad(x, gu, dw, in_scale=s, pad=pad, pad_mode=pad_mode)
             g_w = dw[: prep.co, :, :, : prep.ci].permute(0, 3, 1, 2) * prep.c
         g_s = None
         if d is not None and (need_w or need_s):

@@ -103,7 +103,8 @@ def test_training_steps_match_reference(name, precision, golden_dir):
     gold = np.load(os.path.join(golden_dir, f"{name}.npz"))
     # step 0 depends on the forward only; step 1 and the probes also on one Adam update of
     # every parameter by ~lr*sign(g) -- sign flips of tiny gradients perturb them slightly
-    loose = {"fp32": 2e-2, "bf16": 1e-1}[precision]
+    # (bf16: gradient noise flips the sign of ~1/6 of the +-lr Adam moves, see the yardstick)
+    loose = {"fp32": 2e-2, "bf16": 2e-1}[precision]
     tight = {"fp32": 2e-3, "bf16": 5e-2}[precision]
     bad = []
     for k in gold.files:
