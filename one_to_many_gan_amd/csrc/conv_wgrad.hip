@@ -5,38 +5,62 @@
 // The reduction index m is the SLOW index of both operands in memory (NHWC: channels are
 // contiguous), while the MFMA wants 8 consecutive reduction elements per lane.  Both tiles
 // are therefore staged row-major exactly as they sit in HBM ([32 pixels][channels], 16-B
-// coalesced loads, no transposition on the way in) and the fragments are fetched with the
-// CDNA4 transposing LDS read ds_read_b64_tr_b16: two reads give one lane its 8 consecutive
-// pixels of one channel.  Row stride 2*cols+64 B keeps the four rows of one tr-read on
-// disjoint 64-B bank windows.
+// coalesced buffer loads, no transposition on the way in) and the fragments are fetched with
+// the CDNA4 transposing LDS read ds_read_b64_tr_b16: two reads give one lane its 8
+// consecutive pixels of one channel.  Row stride 2*cols+64 B keeps the four rows of one
+// tr-read on disjoint 64-B bank windows (SQ_LDS_BANK_CONFLICT = 0).
 //
-// Grid = co-tiles x k-tiles x splits; each block reduces its slice of the pixels into a
-// 32x32-tiled fp32 accumulator and adds it to dW with global_atomic_add_f32 (128-B row
-// segments per half-wave: the full-rate atomic shape).  fp32 mode: bf16x3 split as in
-// conv_igemm.hip.
+// Grid = co-tiles x k-tiles x splits, XCD-ordered so that the tiles of one split (which
+// share x and gy) run on one L2.  Each block reduces its slice of the pixels, two LDS stages
+// of 32 pixels (issue-early / write-late), into 32x32-tiled fp32 accumulators and adds them
+// to dW with global_atomic_add_f32 (128-B row segments per half-wave: the full-rate atomic
+// shape).  When a 32-pixel stage lies inside one image row (Wo % 32 == 0: every generator
+// layer) the sample / row part of the gather address is scalar.  fp32 mode: bf16x3 split as
+// in conv_igemm.hip.
 #include "common.h"
 
 namespace {
 
 constexpr int NT = 256;
 constexpr int BMR = 32;  // pixels per stage
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+constexpr unsigned OOB_OFF = 0x80000000u;
 
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+
+template <typename T> struct Stg;
+template <> struct Stg<unsigned short> { u32x4 v; };
+template <> struct Stg<float> { f32x4 a, b; };
+__device__ __forceinline__ void stg_load(Stg<unsigned short>& s, rsrc_t r, unsigned off) {
+  s.v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+}
+__device__ __forceinline__ void stg_load(Stg<float>& s, rsrc_t r, unsigned off) {
+  s.a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
+  s.b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off + 16, 0, 0));
+}
+
+// 8 staged values -> LDS image(s), optionally scaled by 8 per-channel factors
 template <typename T, bool SCALED>
-__device__ __forceinline__ void put8(const T* src, bool ok, const float* sc, char* hi, char* lo,
-                                     int off) {
+__device__ __forceinline__ void put8(const Stg<T>& s, const float* sc, char* hi, char* lo, int off) {
   constexpr bool F32 = sizeof(T) == 4;
-  if (!ok) {
-    *reinterpret_cast<u32x4*>(hi + off) = u32x4{0, 0, 0, 0};
-    if constexpr (F32) *reinterpret_cast<u32x4*>(lo + off) = u32x4{0, 0, 0, 0};
-    return;
-  }
   if constexpr (!F32 && !SCALED) {
-    *reinterpret_cast<u32x4*>(hi + off) = *reinterpret_cast<const u32x4*>(src);
+    *reinterpret_cast<u32x4*>(hi + off) = s.v;
   } else {
     float f[8];
-    load8(src, f);
+    if constexpr (F32) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { f[i] = s.a[i]; f[4 + i] = s.b[i]; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f[2 * i] = __builtin_bit_cast(float, s.v[i] << 16);
+        f[2 * i + 1] = __builtin_bit_cast(float, s.v[i] & 0xffff0000u);
+      }
+    }
     if constexpr (SCALED) {
-      f32x4 s0 = *reinterpret_cast<const f32x4*>(sc), s1 = *reinterpret_cast<const f32x4*>(sc + 4);
+      const f32x4 s0 = *reinterpret_cast<const f32x4*>(sc), s1 = *reinterpret_cast<const f32x4*>(sc + 4);
 #pragma unroll
       for (int i = 0; i < 4; ++i) { f[i] *= s0[i]; f[4 + i] *= s1[i]; }
     }
@@ -55,15 +79,13 @@ __device__ __forceinline__ void put8(const T* src, bool ok, const float* sc, cha
   }
 }
 
-// fragment: column `col` of a row-major [32][cols] bf16 image, rows 8*lh .. 8*lh+7
-__device__ __forceinline__ bf16x8 tr_frag(const char* img, int stride, int colbase, int lane) {
-  const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
-  const int row = 8 * (g >> 1) + q;
-  const int col = colbase + 16 * (g & 1) + 4 * p;
-  const char* a = img + row * stride + col * 2;
+// fragment = 8 consecutive rows (pixels) of one column of a row-major bf16 image.
+// `a` already points at this lane's (row 8*lh + q, column 16*(g&1) + 4p) of the 32x32 block.
+template <int STRIDE>
+__device__ __forceinline__ bf16x8 tr_frag(const char* a) {
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
   s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a));
-  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 4 * stride));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 4 * STRIDE));
   s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(bf16x8, r);
 }
@@ -72,27 +94,29 @@ template <typename T, int BCO, int BKO, int WAVES_CO, int WAVES_K, bool XS, bool
 __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const o2m_wgrad_desc d, int tiles_co,
                                                            int tiles_k, int rows_per_split) {
   constexpr bool F32 = sizeof(T) == 4;
+  constexpr int ES = sizeof(T);
   constexpr int NPLANE = F32 ? 2 : 1;
+  constexpr int NSTAGE = 2;
   constexpr int GSTR = BCO * 2 + 64, XSTR = BKO * 2 + 64;  // row strides (bytes)
   constexpr int G_BYTES = BMR * GSTR, X_BYTES = BMR * XSTR;
   constexpr int STAGE_BYTES = NPLANE * (G_BYTES + X_BYTES);
   constexpr int WCO = BCO / WAVES_CO, WK = BKO / WAVES_K;
   constexpr int TM = WCO / 32, TN = WK / 32;
-  constexpr int GCH = BCO / 8;                        // 16-B chunks per G row
-  constexpr int GLD = (BMR * GCH + NT - 1) / NT;      // G loads per thread per stage
-  constexpr int XLD = BMR * (BKO / 8) / NT;           // X loads per thread per stage (=2)
-  static_assert(WAVES_CO * WAVES_K == 4 && BKO == 128, "layout");
+  constexpr int GCH = BCO / 8;                    // 16-B chunks per G row
+  constexpr int GLD = (BMR * GCH + NT - 1) / NT;  // G loads per thread per stage
+  constexpr int GRS = NT / GCH;                   // G rows covered per pass
+  constexpr int XLD = BMR * (BKO / 8) / NT;       // X loads per thread per stage (= 2)
+  static_assert(WAVES_CO * WAVES_K == 4 && BKO == 128 && NT % GCH == 0, "layout");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  const T* __restrict__ X = static_cast<const T*>(d.x);
-  const T* __restrict__ G = static_cast<const T*>(d.gy);
   const int H = d.H, W = d.W, Ci = d.Ci, Co = d.Co, KH = d.KH, KW = d.KW, pad = d.pad;
   const int Ho = H + 2 * pad - KH + 1, Wo = W + 2 * pad - KW + 1;
   const int HoWo = Ho * Wo;
   const int M = d.B * HoWo;
   const int K = KH * KW * Ci;
   const bool reflect = d.pad_mode == O2M_PAD_REFLECT;
+  const bool aligned = (Wo % BMR) == 0;  // a stage never leaves its image row
 
   int bid = xcd_tile_order(blockIdx.x, gridDim.x);  // a split's tiles share x / gy: one XCD
   const int tk = bid % tiles_k; bid /= tiles_k;
@@ -103,25 +127,107 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const o2m_wgrad_desc 
   const int m_end = min(M, m_begin + rows_per_split);
   if (m_begin >= m_end) return;  // uniform per block
 
+  const rsrc_t xr = make_rsrc(d.x, (unsigned)((size_t)d.B * H * W * Ci * ES));
+  const rsrc_t gr = make_rsrc(d.gy, (unsigned)((size_t)M * Co * ES));
+
   const int tid = threadIdx.x;
-  // X gather: this thread always fetches the same 8 reduction columns (tap, ci0)
+  // ---- G (upstream gradient) loader: rows grow0 + GRS*j, 8 channels at co0 + gc*8 --------
+  const int gc = tid % GCH, grow0 = tid / GCH;
+  const bool gcol_ok = co0 + gc * 8 < Co;
+  const unsigned gbase = (unsigned)(co0 + gc * 8) * ES;  // + m*Co*ES per row
+
+  // ---- X gather: this thread always fetches the same 8 reduction columns (tap, ci0) -----
   const int xc = tid & 15, xr0 = tid >> 4;  // rows xr0 and xr0+16
   const int kx = k0 + xc * 8;
   const bool kxv = kx < K;
   const int tap = kx / Ci, ci0 = kx - tap * Ci;
-  const int kh = tap / KW, kw = tap - kh * KW;
+  const int dy = tap / KW - pad, dx = tap - (tap / KW) * KW - pad;
 
-  // pixel coordinates of this thread's two X rows, advanced incrementally per stage
+  // generic path: per-row pixel coordinates, advanced incrementally per stage
   int pb[XLD], py[XLD], px[XLD];
 #pragma unroll
   for (int j = 0; j < XLD; ++j) {
-    int m = m_begin + xr0 + 16 * j;
+    const int m = m_begin + xr0 + 16 * j;
     pb[j] = m / HoWo;
-    int rem = m - pb[j] * HoWo;
+    const int rem = m - pb[j] * HoWo;
     py[j] = rem / Wo;
     px[j] = rem - py[j] * Wo;
   }
+  // aligned path: (sample, row) of the whole stage are scalar
+  int sb = m_begin / HoWo, sy = (m_begin - sb * HoWo) / Wo, sx = m_begin - sb * HoWo - sy * Wo;
 
+  Stg<T> sg[GLD], sx_[XLD];
+  int xsamp[XLD];  // sample index of each staged X row (only read when XS)
+
+  auto load_stage = [&](int ms) {
+#pragma unroll
+    for (int j = 0; j < GLD; ++j) {
+      const int m = ms + grow0 + GRS * j;
+      const bool ok = gcol_ok && (GLD * GRS == BMR || grow0 + GRS * j < BMR) && m < m_end;
+      stg_load(sg[j], gr, ok ? gbase + (unsigned)m * (unsigned)(Co * ES) : OOB_OFF);
+    }
+    if (aligned) {
+      int iy = sy + dy;  // per-thread only through dy (constant): cheap
+      bool rowok = kxv;
+      if (reflect) iy = iy < 0 ? -iy : (iy >= H ? 2 * H - 2 - iy : iy);
+      else rowok = rowok && (unsigned)iy < (unsigned)H;
+      const int rowbase = (sb * H + iy) * W;
+#pragma unroll
+      for (int j = 0; j < XLD; ++j) {
+        int ix = sx + xr0 + 16 * j + dx;
+        bool ok = rowok && ms + xr0 + 16 * j < m_end;
+        if (reflect) ix = ix < 0 ? -ix : (ix >= W ? 2 * W - 2 - ix : ix);
+        else ok = ok && (unsigned)ix < (unsigned)W;
+        stg_load(sx_[j], xr, ok ? (unsigned)((rowbase + ix) * Ci + ci0) * ES : OOB_OFF);
+        xsamp[j] = sb;
+      }
+      sx += BMR;
+      if (sx >= Wo) { sx = 0; if (++sy >= Ho) { sy = 0; ++sb; } }
+    } else {
+#pragma unroll
+      for (int j = 0; j < XLD; ++j) {
+        int iy = py[j] + dy, ix = px[j] + dx;
+        bool ok = kxv && ms + xr0 + 16 * j < m_end;
+        if (reflect) {
+          iy = iy < 0 ? -iy : (iy >= H ? 2 * H - 2 - iy : iy);
+          ix = ix < 0 ? -ix : (ix >= W ? 2 * W - 2 - ix : ix);
+        } else {
+          ok = ok && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        }
+        stg_load(sx_[j], xr, ok ? (unsigned)(((pb[j] * H + iy) * W + ix) * Ci + ci0) * ES : OOB_OFF);
+        xsamp[j] = pb[j];
+        px[j] += BMR;
+        while (px[j] >= Wo) { px[j] -= Wo; ++py[j]; }
+        while (py[j] >= Ho) { py[j] -= Ho; ++pb[j]; }
+      }
+    }
+  };
+
+  auto store_stage = [&](int stage, int ms) {
+    char* base = smem + stage * STAGE_BYTES;
+    char* g_hi = base;
+    char* g_lo = base + G_BYTES;
+    char* x_hi = base + NPLANE * G_BYTES;
+    char* x_lo = x_hi + X_BYTES;
+#pragma unroll
+    for (int j = 0; j < GLD; ++j) {
+      if (GLD * GRS != BMR && grow0 + GRS * j >= BMR) continue;
+      const float* sc = nullptr;
+      if constexpr (GS) {
+        const int m = min(ms + grow0 + GRS * j, M - 1);
+        sc = d.gy_scale + (size_t)(m / HoWo) * Co + min(co0 + gc * 8, Co - 8);
+      }
+      put8<T, GS>(sg[j], sc, g_hi, g_lo, (grow0 + GRS * j) * GSTR + gc * 16);
+    }
+#pragma unroll
+    for (int j = 0; j < XLD; ++j) {
+      const float* sc = nullptr;
+      if constexpr (XS) sc = d.in_scale + (size_t)min(xsamp[j], d.B - 1) * Ci + (kxv ? ci0 : 0);
+      put8<T, XS>(sx_[j], sc, x_hi, x_lo, (xr0 + 16 * j) * XSTR + xc * 16);
+    }
+  };
+
+  // ---- accumulators and hoisted fragment addresses ----------------------------------------
   const int wave = tid >> 6, lane = tid & 63;
   const int wco = (wave / WAVES_K) * WCO, wk = (wave % WAVES_K) * WK;
   f32x16 acc[TM][TN];
@@ -131,63 +237,29 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const o2m_wgrad_desc 
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int fg = lane >> 4, fi = lane & 15, fq = fi >> 2, fp = fi & 3;
+  const int frow = 8 * (fg >> 1) + fq, fcol = 16 * (fg & 1) + 4 * fp;
+  const int gfrag = frow * GSTR + (wco + fcol) * 2;  // + i*64 + ks*16*GSTR   (immediates)
+  const int xfrag = frow * XSTR + (wk + fcol) * 2;   // + j*64 + ks*16*XSTR
 
-  char* g_hi = smem;
-  char* g_lo = smem + G_BYTES;
-  char* x_hi = smem + NPLANE * G_BYTES;
-  char* x_lo = x_hi + X_BYTES;
-
-  for (int ms = m_begin; ms < m_end; ms += BMR) {
-    // ---- stage: global -> LDS (row-major, as in HBM) ---------------------------------
-#pragma unroll
-    for (int j = 0; j < GLD; ++j) {
-      const int idx = tid + NT * j;
-      if (idx < BMR * GCH) {
-        const int row = idx / GCH, c = idx - row * GCH;
-        const int m = ms + row, co = co0 + c * 8;
-        const bool ok = m < m_end && co < Co;
-        const float* sc = nullptr;
-        if constexpr (GS) sc = d.gy_scale + (size_t)(ok ? m / HoWo : 0) * Co + (ok ? co : 0);
-        put8<T, GS>(G + (size_t)m * Co + co, ok, sc, g_hi, g_lo, row * GSTR + c * 16);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < XLD; ++j) {
-      const int row = xr0 + 16 * j;
-      const int m = ms + row;
-      int iy = py[j] + kh - pad, ix = px[j] + kw - pad;
-      bool ok = kxv && m < m_end;
-      if (reflect) {
-        iy = iy < 0 ? -iy : (iy >= H ? 2 * H - 2 - iy : iy);
-        ix = ix < 0 ? -ix : (ix >= W ? 2 * W - 2 - ix : ix);
-      } else {
-        ok = ok && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-      }
-      const size_t off = ok ? ((size_t)(pb[j] * H + iy) * W + ix) * Ci + ci0 : 0;
-      const float* sc = nullptr;
-      if constexpr (XS) sc = d.in_scale + (size_t)(ok ? pb[j] : 0) * Ci + ci0;
-      put8<T, XS>(X + off, ok, sc, x_hi, x_lo, row * XSTR + xc * 16);
-      // advance this row by one stage (BMR pixels)
-      px[j] += BMR;
-      while (px[j] >= Wo) { px[j] -= Wo; ++py[j]; }
-      while (py[j] >= Ho) { py[j] -= Ho; ++pb[j]; }
-    }
-    __syncthreads();
-
-    // ---- MFMA: D[co][k] += G^T . X over this stage's 32 pixels ------------------------
+  auto compute = [&](int stage) {
+    const char* base = smem + stage * STAGE_BYTES;
+    const char* g_hi = base + gfrag;
+    const char* g_lo = g_hi + G_BYTES;
+    const char* x_hi = base + NPLANE * G_BYTES + xfrag;
+    const char* x_lo = x_hi + X_BYTES;
 #pragma unroll
     for (int ks = 0; ks < BMR / 16; ++ks) {
-      const int roff = ks * 16;
       bf16x8 ah[TM], bh[TN], al[F32 ? TM : 1], bl[F32 ? TN : 1];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        ah[i] = tr_frag(g_hi + roff * GSTR, GSTR, wco + i * 32, lane);
-        if constexpr (F32) al[i] = tr_frag(g_lo + roff * GSTR, GSTR, wco + i * 32, lane);
+        ah[i] = tr_frag<GSTR>(g_hi + ks * 16 * GSTR + i * 64);
+        if constexpr (F32) al[i] = tr_frag<GSTR>(g_lo + ks * 16 * GSTR + i * 64);
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        bh[j] = tr_frag(x_hi + roff * XSTR, XSTR, wk + j * 32, lane);
-        if constexpr (F32) bl[j] = tr_frag(x_lo + roff * XSTR, XSTR, wk + j * 32, lane);
+        bh[j] = tr_frag<XSTR>(x_hi + ks * 16 * XSTR + j * 64);
+        if constexpr (F32) bl[j] = tr_frag<XSTR>(x_lo + ks * 16 * XSTR + j * 64);
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -200,7 +272,20 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const o2m_wgrad_desc 
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
     }
+  };
+
+  // ---- main loop ------------------------------------------------------------------------------
+  load_stage(m_begin);
+  store_stage(0, m_begin);
+  __syncthreads();
+  int cur = 0;
+  for (int ms = m_begin; ms < m_end; ms += BMR) {
+    const bool more = ms + BMR < m_end;
+    if (more) load_stage(ms + BMR);
+    compute(cur);
+    if (more) store_stage(cur ^ 1, ms + BMR);
     __syncthreads();
+    cur ^= 1;
   }
 
   // ---- epilogue: lane owns one k column; fp32 atomics, 128-B segments per half-wave ----
@@ -223,15 +308,18 @@ template <typename T, int BCO, int WAVES_CO, int WAVES_K>
 int launch_cfg(const o2m_wgrad_desc& d, hipStream_t s) {
   constexpr int BKO = 128;
   constexpr bool F32 = sizeof(T) == 4;
-  constexpr int lds = (F32 ? 2 : 1) * BMR * ((BCO * 2 + 64) + (BKO * 2 + 64));
+  constexpr int lds = 2 * (F32 ? 2 : 1) * BMR * ((BCO * 2 + 64) + (BKO * 2 + 64));
   const int Ho = d.H + 2 * d.pad - d.KH + 1, Wo = d.W + 2 * d.pad - d.KW + 1;
   const long M = (long)d.B * Ho * Wo;
   const int K = d.KH * d.KW * d.Ci;
   const int tiles_co = (d.Co + BCO - 1) / BCO, tiles_k = (K + BKO - 1) / BKO;
   long splits = d.splits;
   if (splits <= 0) {
-    splits = 2048 / ((long)tiles_co * tiles_k);       // ~8 blocks per CU in flight
-    const long max_splits = (M + 4 * BMR - 1) / (4 * BMR);  // >= 4 stages per block
+    // every split adds Co*K fp32 atomics: ~900 blocks when that slab is >= 1 MB (measured
+    // optimum on the 256->256, 256->128 and 256->512 layers), ~2048 when it is small
+    const long target = (long)d.Co * K * 4 >= (1 << 20) ? 900 : 2048;
+    splits = (target + (long)tiles_co * tiles_k - 1) / ((long)tiles_co * tiles_k);
+    const long max_splits = (M + 8 * BMR - 1) / (8 * BMR);  // >= 8 stages per block
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
   }
@@ -241,6 +329,8 @@ int launch_cfg(const o2m_wgrad_desc& d, hipStream_t s) {
   const long blocks = splits * tiles_co * tiles_k;
   if (blocks > 0x7fffffffL) return O2M_ERR_BAD_ARG;
   auto go = [&](auto kern) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NT), lds, s, d, tiles_co, tiles_k, (int)rows);
   };
   const bool xs = d.in_scale != nullptr, gs = d.gy_scale != nullptr;
@@ -268,7 +358,10 @@ extern "C" int o2m_conv2d_wgrad(const o2m_wgrad_desc* d, void* stream) {
   if (d->H + 2 * d->pad < d->KH || d->W + 2 * d->pad < d->KW) return O2M_ERR_BAD_ARG;
   if (d->pad_mode == O2M_PAD_REFLECT && (d->pad >= d->H || d->pad >= d->W)) return O2M_ERR_BAD_ARG;
   if (d->pad_mode != O2M_PAD_ZERO && d->pad_mode != O2M_PAD_REFLECT) return O2M_ERR_BAD_ARG;
-  if ((long)d->B * d->H * d->W * (long)d->Ci > 0x7fffffffL) return O2M_ERR_UNSUPPORTED;
+  const long esz = d->dtype == O2M_F32 ? 4 : 2;
+  const long howo = (long)(d->H + 2 * d->pad - d->KH + 1) * (d->W + 2 * d->pad - d->KW + 1);
+  if ((long)d->B * d->H * d->W * (long)d->Ci * esz > 0x7fffffffL) return O2M_ERR_UNSUPPORTED;
+  if ((long)d->B * howo * (long)d->Co * esz > 0x7fffffffL) return O2M_ERR_UNSUPPORTED;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (d->dtype == O2M_BF16) return launch_dtype<unsigned short>(*d, s);
   if (d->dtype == O2M_F32) return launch_dtype<float>(*d, s);

@@ -54,6 +54,11 @@ def _tolerance(name, key, precision):
             return 3e-2
         return 1e-3
     floor = 2e-2 if grad else 1e-2
+    if grad and key.endswith("bias") and name.startswith(NET_CASES):
+        # a conv bias gradient is a SIGNED sum over every pixel of bf16-rounded terms: with few
+        # channels (the 1- or 3-channel image convs) it cancels to a small number whose
+        # relative error the per-tensor yardstick does not bound
+        floor = 1e-1
     return max(floor, 2.0 * _YARD.get(name, {}).get(key, 0.0))
 
 

@@ -33,22 +33,27 @@ def timeit(fn, iters=20):
     return e0.elapsed_time(e1) / iters * 1e-3
 
 
-dt = torch.bfloat16
-which = sys.argv[1] if len(sys.argv) > 1 else "all"
-for (B, Hh, Ww, Ci, Co, k, pad, refl) in SHAPES:
-    x = torch.randn(B, Hh, Ww, Ci, device=dev).to(dt)
-    w = (torch.randn(Co, k, k, Ci, device=dev) / (Ci * k * k) ** 0.5).to(dt)
-    ho, wo = Hh + 2 * pad - k + 1, Ww + 2 * pad - k + 1
-    y = torch.empty(B, ho, wo, Co, device=dev, dtype=dt)
-    pm = H.PAD_REFLECT if refl else H.PAD_ZERO
-    flops = 2.0 * B * ho * wo * Co * k * k * Ci
-    line = f"B{B} {Hh}x{Ww} {Ci}->{Co} k{k}: "
-    if which in ("all", "fwd"):
-        t = timeit(lambda: H.conv2d_fwd(x, w, y, pad=pad, pad_mode=pm, act=H.ACT_RELU))
-        line += f"fwd {t*1e6:8.1f} us {flops/t/1e12:7.1f} TF/s | "
-    if which in ("all", "wgrad"):
-        gy = torch.randn(B, ho, wo, Co, device=dev).to(dt)
-        dw = torch.zeros(Co, k, k, Ci, device=dev)
-        t = timeit(lambda: H.conv2d_wgrad(x, gy, dw, pad=pad, pad_mode=pm))
-        line += f"wgrad {t*1e6:8.1f} us {flops/t/1e12:7.1f} TF/s"
-    print(line, flush=True)
+def main():
+  dt = torch.bfloat16
+  which = sys.argv[1] if len(sys.argv) > 1 else "all"
+  for (B, Hh, Ww, Ci, Co, k, pad, refl) in SHAPES:
+      x = torch.randn(B, Hh, Ww, Ci, device=dev).to(dt)
+      w = (torch.randn(Co, k, k, Ci, device=dev) / (Ci * k * k) ** 0.5).to(dt)
+      ho, wo = Hh + 2 * pad - k + 1, Ww + 2 * pad - k + 1
+      y = torch.empty(B, ho, wo, Co, device=dev, dtype=dt)
+      pm = H.PAD_REFLECT if refl else H.PAD_ZERO
+      flops = 2.0 * B * ho * wo * Co * k * k * Ci
+      line = f"B{B} {Hh}x{Ww} {Ci}->{Co} k{k}: "
+      if which in ("all", "fwd"):
+          t = timeit(lambda: H.conv2d_fwd(x, w, y, pad=pad, pad_mode=pm, act=H.ACT_RELU))
+          line += f"fwd {t*1e6:8.1f} us {flops/t/1e12:7.1f} TF/s | "
+      if which in ("all", "wgrad"):
+          gy = torch.randn(B, ho, wo, Co, device=dev).to(dt)
+          dw = torch.zeros(Co, k, k, Ci, device=dev)
+          t = timeit(lambda: H.conv2d_wgrad(x, gy, dw, pad=pad, pad_mode=pm))
+          line += f"wgrad {t*1e6:8.1f} us {flops/t/1e12:7.1f} TF/s"
+      print(line, flush=True)
+
+
+if __name__ == "__main__":
+    main()
