@@ -88,6 +88,23 @@ int o2m_conv2d_fwd(const o2m_conv_desc* d, void* stream);
 int o2m_modulate_weights(const float* w32, const float* s, void* out, int32_t B, int32_t Co,
                          int32_t KK, int32_t Ci, int32_t dtype, void* stream);
 
+/* Style path of the modulated conv (to_style linear + demodulation, layers.py:138-161) and
+ * its backward, B x C sized (see csrc/style.hip for the formulas).
+ *   fwd: w [B][WD], Ws [Ci][WD] (raw to_style weight, cs = 1/sqrt(WD) applied inside), bs [Ci],
+ *        Qt [Cip][Cop] = transposed Q (NULL with d NULL: no demodulation)
+ *        -> s [B][Cip] (zero beyond Ci), d [B][Cop].
+ *   bwd: sums [B][2][Cop] from o2m_act_bwd_reduce, bias [Cop] or NULL, dots [B][Cip] from
+ *        o2m_fold_scale_dot, Q [Cop][Cip] -> e [B][Cop], gs [B][Cip] (workspaces),
+ *        gw [B][WD], gWs [Ci][WD], gbs [Ci], gq [Cop][Cip] = dL/dQ.   d NULL: no demodulation.
+ */
+int o2m_style_fwd(const float* w, const float* Ws, const float* bs, const float* Qt, float* s,
+                  float* d, int32_t B, int32_t WD, int32_t Ci, int32_t Cip, int32_t Cop, float cs,
+                  float eps, void* stream);
+int o2m_style_bwd(const float* sums, const float* bias, const float* dots, const float* s,
+                  const float* d, const float* Q, const float* w, const float* Ws, float* e,
+                  float* gs, float* gw, float* gWs, float* gbs, float* gq, int32_t B, int32_t WD,
+                  int32_t Ci, int32_t Cip, int32_t Cop, float cs, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Weight gradient of the convolution above (the wgrad half of aten::convolution_backward
  * for the same call sites), split over the B*Ho*Wo reduction, fp32 atomics into dw:
@@ -110,9 +127,9 @@ int o2m_conv2d_wgrad(const o2m_wgrad_desc* d, void* stream);
 /* ------------------------------------------------------------------------------------
  * Backward of the fused epilogue: gu = g * act'(y), plus the per-(b,c) sums the
  * modulated conv and the bias need:
- *   sums[b,c,0] = sum_p gu ,  sums[b,c,1] = sum_p gu * (y - residual)
+ *   sums[b,0,c] = sum_p gu ,  sums[b,1,c] = sum_p gu * (y - residual)
  * (second sum gives d loss / d out_scale = sums1 / out_scale for act in {none, relu}).
- * sums is fp32 [B][C][2], zeroed by the caller (accumulated with atomics).  If out_mul
+ * sums is fp32 [B][2][C], zeroed by the caller (accumulated with atomics).  If out_mul
  * ([B][C] fp32) is given the STORED tensor is gu * out_mul[b,c] (the demodulation factor is
  * folded here so that dgrad and wgrad of the modulated conv read it pre-scaled); the sums
  * always use the unscaled gu.

@@ -44,6 +44,8 @@ SIGNATURES = {
     "o2m_abi_version": (_i32, []),
     "o2m_conv2d_fwd": (_i32, [C.POINTER(ConvDesc), _vp]),
     "o2m_conv2d_wgrad": (_i32, [C.POINTER(WgradDesc), _vp]),
+    "o2m_style_fwd": (_i32, [_vp] * 6 + [_i32] * 5 + [_f32, _f32, _vp]),
+    "o2m_style_bwd": (_i32, [_vp] * 14 + [_i32] * 5 + [_f32, _vp]),
     "o2m_act_bwd_reduce": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "o2m_modulate_weights": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "o2m_fold_scale_dot": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
@@ -167,6 +169,23 @@ def act_bwd_reduce(g, y, residual, out_mul, gu, sums, act):
     B, P, Cn = g.shape[0], g.shape[1] * g.shape[2], g.shape[3]
     check(lib().o2m_act_bwd_reduce(ptr(g), ptr(y), ptr(residual), ptr(out_mul), ptr(gu), ptr(sums), B, P,
                                    Cn, act, dtype_code(g.dtype), _stream(g)), "o2m_act_bwd_reduce")
+
+
+def style_fwd(w, ws, bs, qt, s, d, ci, cs, eps):
+    B, WD = w.shape
+    cip = s.shape[1]
+    cop = d.shape[1] if d is not None else 0
+    check(lib().o2m_style_fwd(ptr(w), ptr(ws), ptr(bs), ptr(qt), ptr(s), ptr(d), B, WD, ci, cip, cop, cs,
+                              eps, _stream(s)), "o2m_style_fwd")
+
+
+def style_bwd(sums, bias, dots, s, d, q, w, ws, e, gs, gw, gws, gbs, gq, ci, cs):
+    B, WD = w.shape
+    cip = s.shape[1]
+    cop = d.shape[1] if d is not None else 8
+    check(lib().o2m_style_bwd(ptr(sums), ptr(bias), ptr(dots), ptr(s), ptr(d), ptr(q), ptr(w), ptr(ws),
+                              ptr(e), ptr(gs), ptr(gw), ptr(gws), ptr(gbs), ptr(gq), B, WD, ci, cip, cop, cs,
+                              _stream(s)), "o2m_style_bwd")
 
 
 def modulate_weights(w32, s, out):

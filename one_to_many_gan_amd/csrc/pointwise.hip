@@ -18,8 +18,8 @@ __host__ __device__ inline ChanGeom chan_geom(int B, int P, int C) {
   ChanGeom g;
   g.CV = C / 8;
   g.PL = g.CV >= NT ? 1 : NT / g.CV;
-  // aim for ~2048 blocks overall, at least 8 pixels per pixel lane
-  int want = (2048 + B - 1) / B;
+  // aim for ~1024 blocks overall (4 per CU), at least 8 pixels per pixel lane
+  int want = (1024 + B - 1) / B;
   int maxc = (P + g.PL * 8 - 1) / (g.PL * 8);
   g.nchunks = want < maxc ? want : maxc;
   if (g.nchunks < 1) g.nchunks = 1;
@@ -79,14 +79,14 @@ __global__ __launch_bounds__(NT) void act_bwd_reduce_kernel(const T* g, const T*
     }
   }
   lanes_reduce<16>(acc, cv, pl, gm.CV, gm.PL, sm);
+  // coalesce: [2][C] in LDS, then consecutive lanes add consecutive floats (256-B atomics)
+  __syncthreads();
   if (pl == 0) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      float* s = sums + ((size_t)b * C + cv * 8 + i) * 2;
-      atomicAdd(s, acc[i]);
-      atomicAdd(s + 1, acc[8 + i]);
-    }
+    for (int i = 0; i < 8; ++i) { sm[cv * 8 + i] = acc[i]; sm[C + cv * 8 + i] = acc[8 + i]; }
   }
+  __syncthreads();
+  for (int t = threadIdx.x; t < 2 * C; t += NT) atomicAdd(sums + (size_t)b * 2 * C + t, sm[t]);
 }
 
 // ---- reflect-pad backward (fold) + style scale + style dot ----------------------------------
@@ -140,9 +140,12 @@ __global__ __launch_bounds__(NT) void fold_scale_dot_kernel(const T* gpad, const
   }
   if (dots) {
     lanes_reduce<8>(acc, cv, pl, gm.CV, gm.PL, sm);
+    __syncthreads();
     if (pl == 0)
 #pragma unroll
-      for (int i = 0; i < 8; ++i) atomicAdd(dots + (size_t)b * C + cv * 8 + i, acc[i]);
+      for (int i = 0; i < 8; ++i) sm[cv * 8 + i] = acc[i];
+    __syncthreads();
+    for (int t = threadIdx.x; t < C; t += NT) atomicAdd(dots + (size_t)b * C + t, sm[t]);
   }
 }
 

@@ -123,7 +123,7 @@ class Conv2dWeightModulate(nn.Module):
         return ops.conv2d(
             t, self.weight.weight, self.bias if self.use_bias else None, self._prepared(),
             pad=reflect or self.padding, pad_mode=H.PAD_REFLECT if reflect else H.PAD_ZERO,
-            act=act, style=self.to_style(w), residual=residual,
+            act=act, style=(w, self.to_style.weight.weight, self.to_style.bias), residual=residual,
             demodulate=self.demodulate, eps=self.eps)
 
     def forward(self, x: torch.Tensor, w: torch.Tensor):

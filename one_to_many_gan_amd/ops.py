@@ -131,7 +131,8 @@ class PreparedWeight:
                 w_f = full.to(compute_dtype()).contiguous()
                 w_d = full.flip(1, 2).permute(3, 1, 2, 0).to(compute_dtype()).contiguous()
                 q = full.square().sum(dim=(1, 2)).contiguous() if self.need_q else None
-            self._val = (w_f, w_d, q, full if self.need_q else None)
+                qt = q.t().contiguous() if self.need_q else None
+            self._val = (w_f, w_d, q, full if self.need_q else None, qt)
             self._key = key
         return self._val
 
@@ -149,21 +150,25 @@ def _pad_cols(t: torch.Tensor, n: int) -> torch.Tensor:
 
 
 class _ConvFn(torch.autograd.Function):
-    """y = act(d[b,o] * conv(W*c, pad(x * s[b,i])) + bias) + residual, d = demodulation."""
+    """y = act(d[b,o] * conv(W*c, pad(x * s[b,i])) + bias) + residual with
+    s = to_style(w_style) and d = demodulation (both computed by o2m_style_fwd)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, style, residual, prep, pad, pad_mode, act, demodulate, eps):
-        w_f, w_d, q, w32 = prep.get()
+    def forward(ctx, x, weight, bias, w_style, ts_weight, ts_bias, residual, prep, pad, pad_mode, act,
+                demodulate, eps):
+        w_f, w_d, q, w32, qt = prep.get()
         B, Hh, Ww, cip = x.shape
         if cip != prep.cip:
             raise RuntimeError(f"conv input has {cip} channels, layer expects {prep.cip} (padded)")
         ho, wo = Hh + 2 * pad - prep.kh + 1, Ww + 2 * pad - prep.kw + 1
-        s = d = None
-        if style is not None:
-            s = _pad_cols(style, prep.cip)
-            if demodulate:
-                d = torch.rsqrt(torch.addmm(torch.full((1, 1), eps, device=x.device), s * s, q.t()))
-                d = d.contiguous()
+        s = d = wv = ws = None
+        if w_style is not None:
+            wv = w_style.detach().float().contiguous()
+            ws = ts_weight.detach().float().contiguous()
+            s = torch.empty((B, prep.cip), dtype=torch.float32, device=x.device)
+            d = torch.empty((B, prep.cop), dtype=torch.float32, device=x.device) if demodulate else None
+            H.style_fwd(wv, ws, ts_bias.detach().float().contiguous(), qt if demodulate else None, s, d,
+                        prep.ci, 1.0 / math.sqrt(wv.shape[1]), eps)
         bias_p = None
         if bias is not None:
             bias_p = torch.zeros(prep.cop, dtype=torch.float32, device=x.device)
@@ -181,23 +186,25 @@ class _ConvFn(torch.autograd.Function):
                          pad=pad, pad_mode=pad_mode, act=act)
         ctx.prep, ctx.pad, ctx.pad_mode, ctx.act = prep, pad, pad_mode, act
         ctx.has_bias, ctx.has_res = bias is not None, residual is not None
-        ctx.save_for_backward(x, y, residual, s, d, weight, bias_p)
+        ctx.save_for_backward(x, y, residual, s, d, weight, bias_p, wv, ws)
         return y
 
     @staticmethod
     def backward(ctx, g):
-        x, y, residual, s, d, weight, bias_p = ctx.saved_tensors
+        x, y, residual, s, d, weight, bias_p, wv, ws = ctx.saved_tensors
         prep, pad, pad_mode, act = ctx.prep, ctx.pad, ctx.pad_mode, ctx.act
-        w_f, w_d, q, _ = prep.get()
+        w_f, w_d, q, _, _ = prep.get()
         g = g.contiguous()
         B, Hh, Ww, cip = x.shape
-        need_x, need_w, need_b, need_s = ctx.needs_input_grad[0:4]
-        need_res = ctx.needs_input_grad[4]
+        need_x, need_w, need_b = ctx.needs_input_grad[0:3]
+        need_s = s is not None and any(ctx.needs_input_grad[3:6])
+        need_res = ctx.needs_input_grad[6]
+        dev = g.device
 
         sums = None
         if act != H.ACT_NONE or d is not None:
             gu = torch.empty_like(g)
-            sums = torch.zeros((B, prep.cop, 2), dtype=torch.float32, device=g.device)
+            sums = torch.zeros((B, 2, prep.cop), dtype=torch.float32, device=dev)
             # u = y - residual = act(pre); the stored tensor is gu * d (demodulation folded in)
             H.act_bwd_reduce(g, y, residual, d, gu, sums, act)
         else:
@@ -205,53 +212,60 @@ class _ConvFn(torch.autograd.Function):
 
         g_bias = None
         if ctx.has_bias and need_b:
-            tot = sums[:, :, 0].sum(0) if sums is not None else gu.float().sum(dim=(0, 1, 2))
+            tot = sums[:, 0].sum(0) if sums is not None else gu.float().sum(dim=(0, 1, 2))
             g_bias = tot[: prep.co].to(weight.dtype)
 
         g_x = dots = None
-        if need_x or (need_s and s is not None):
+        if need_x or need_s:
             kpad = prep.kh - 1 - (0 if pad_mode == H.PAD_REFLECT else pad)
             hp = Hh + (2 * pad if pad_mode == H.PAD_REFLECT else 0)
             wp = Ww + (2 * pad if pad_mode == H.PAD_REFLECT else 0)
-            gxp = torch.empty((B, hp, wp, cip), dtype=g.dtype, device=g.device)
+            gxp = torch.empty((B, hp, wp, cip), dtype=g.dtype, device=dev)
             H.conv2d_fwd(gu, w_d, gxp, pad=kpad, pad_mode=H.PAD_ZERO, act=H.ACT_NONE)
             if s is not None or pad_mode == H.PAD_REFLECT:
                 g_x = torch.empty_like(x)
                 if s is not None:
-                    dots = torch.zeros((B, cip), dtype=torch.float32, device=g.device)
+                    dots = torch.zeros((B, cip), dtype=torch.float32, device=dev)
                 H.fold_scale_dot(gxp, x if s is not None else None, s, g_x, dots,
                                  pad if pad_mode == H.PAD_REFLECT else 0)
             else:
                 g_x = gxp
 
-        g_w = e = None
+        g_w = None
         if need_w:
-            dw = torch.zeros((prep.cop, prep.kh, prep.kw, cip), dtype=torch.float32, device=g.device)
+            dw = torch.zeros((prep.cop, prep.kh, prep.kw, cip), dtype=torch.float32, device=dev)
             H.conv2d_wgrad(x, gu, dw, in_scale=s, pad=pad, pad_mode=pad_mode)
             g_w = dw[: prep.co, :, :, : prep.ci].permute(0, 3, 1, 2) * prep.c
-        g_s = None
-        if d is not None and (need_w or need_s):
-            # demodulation chain: d = (s^2 Q^T + eps)^(-1/2);  dL/dd = sums[...,1] / d
-            # sum_p gu*z with z = (u - bias)/d  ->  dL/d(s^2 Q^T) = -(1/2) d^3 * that
-            s1 = sums[:, :, 1] if bias_p is None else sums[:, :, 1] - bias_p * sums[:, :, 0]
-            e = s1 * (-0.5) * d * d
-            if need_w:
-                gq = e.t() @ (s * s)  # [cop, cip]
+
+        g_ws = g_tw = g_tb = None
+        if s is not None and (need_s or (need_w and d is not None)):
+            if dots is None:
+                dots = torch.zeros((B, cip), dtype=torch.float32, device=dev)
+            wd_ = wv.shape[1]
+            e = torch.empty((B, prep.cop), dtype=torch.float32, device=dev) if d is not None else None
+            gs = torch.empty((B, cip), dtype=torch.float32, device=dev)
+            g_ws = torch.empty((B, wd_), dtype=torch.float32, device=dev)
+            g_tw = torch.empty((prep.ci, wd_), dtype=torch.float32, device=dev)
+            g_tb = torch.empty((prep.ci,), dtype=torch.float32, device=dev)
+            gq = torch.empty((prep.cop, cip), dtype=torch.float32, device=dev) if d is not None else None
+            H.style_bwd(sums, bias_p, dots, s, d, q, wv, ws, e, gs, g_ws, g_tw, g_tb, gq, prep.ci,
+                        1.0 / math.sqrt(wd_))
+            if need_w and gq is not None:
+                # Q = c^2 sum_k W^2  ->  dL/dW += dL/dQ * 2 c^2 W
                 g_w = g_w + gq[: prep.co, : prep.ci, None, None] * (2.0 * prep.c * prep.c) * weight.detach().float()
-        if need_s and s is not None:
-            g_s = dots
-            if e is not None:
-                g_s = g_s + 2.0 * s * (e @ q)
-            g_s = g_s[:, : prep.ci]
         if g_w is not None:
             g_w = g_w.to(weight.dtype).contiguous()
         g_res = g if (ctx.has_res and need_res) else None
-        return (g_x if need_x else None, g_w, g_bias, g_s, g_res, None, None, None, None, None, None)
+        return (g_x if need_x else None, g_w, g_bias, g_ws, g_tw, g_tb, g_res,
+                None, None, None, None, None, None)
 
 
 def conv2d(x, weight, bias, prep, *, pad, pad_mode=H.PAD_ZERO, act=H.ACT_NONE, style=None,
            residual=None, demodulate=True, eps=1e-8):
-    return _ConvFn.apply(x, weight, bias, style, residual, prep, pad, pad_mode, act, demodulate, eps)
+    """``style`` = (w, to_style.weight, to_style.bias) for the modulated conv, else None."""
+    w_style, ts_w, ts_b = style if style is not None else (None, None, None)
+    return _ConvFn.apply(x, weight, bias, w_style, ts_w, ts_b, residual, prep, pad, pad_mode, act,
+                         demodulate, eps)
 
 
 # --------------------------------------------------------------------------- instance norm
