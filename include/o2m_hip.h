@@ -95,7 +95,8 @@ int o2m_modulate_weights(const float* w32, const float* s, void* out, int32_t B,
  *        -> s [B][Cip] (zero beyond Ci), d [B][Cop].
  *   bwd: sums [B][2][Cop] from o2m_act_bwd_reduce, bias [Cop] or NULL, dots [B][Cip] from
  *        o2m_fold_scale_dot, Q [Cop][Cip] -> e [B][Cop], gs [B][Cip] (workspaces),
- *        gw [B][WD], gWs [Ci][WD], gbs [Ci], gq [Cop][Cip] = dL/dQ.   d NULL: no demodulation.
+ *        gw [B][WD], gWs [Ci][WD], gbs [Ci]; gq [Cop][Cip] += dL/dQ (accumulated: the layer may be
+ *        used several times in one backward).   d NULL: no demodulation.
  */
 int o2m_style_fwd(const float* w, const float* Ws, const float* bs, const float* Qt, float* s,
                   float* d, int32_t B, int32_t WD, int32_t Ci, int32_t Cip, int32_t Cop, float cs,
@@ -123,6 +124,16 @@ typedef struct {
   int32_t reserved[5];
 } o2m_wgrad_desc;
 int o2m_conv2d_wgrad(const o2m_wgrad_desc* d, void* stream);
+
+/* End-of-backward conversion of an accumulated weight gradient to the parameter layout:
+ *   grad[o][i][kh][kw] += c * ( acc[o][kh][kw][i] + 2 * gq[o][i] * w32[o][kh][kw][i] )
+ * and acc / gq are cleared.  acc: fp32 [Cop][KK][Cip] that o2m_conv2d_wgrad added into over
+ * every use of the layer; gq (NULL for plain convs): dL/dQ from o2m_style_bwd; w32 = W*c in the
+ * same layout; grad: the parameter's .grad, [Co][Ci][KH][KW].  Replaces the permute / scale /
+ * AccumulateGrad chain of eager autograd (layers.py:19-24: d/dW = c * d/d(W*c)).
+ */
+int o2m_wgrad_finalize(float* acc, float* gq, const float* w32, float* grad, int32_t Co, int32_t Ci,
+                       int32_t KK, int32_t Cop, int32_t Cip, float c, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Backward of the fused epilogue: gu = g * act'(y), plus the per-(b,c) sums the

@@ -44,6 +44,7 @@ SIGNATURES = {
     "o2m_abi_version": (_i32, []),
     "o2m_conv2d_fwd": (_i32, [C.POINTER(ConvDesc), _vp]),
     "o2m_conv2d_wgrad": (_i32, [C.POINTER(WgradDesc), _vp]),
+    "o2m_wgrad_finalize": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
     "o2m_style_fwd": (_i32, [_vp] * 6 + [_i32] * 5 + [_f32, _f32, _vp]),
     "o2m_style_bwd": (_i32, [_vp] * 14 + [_i32] * 5 + [_f32, _vp]),
     "o2m_act_bwd_reduce": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
@@ -186,6 +187,12 @@ def style_bwd(sums, bias, dots, s, d, q, w, ws, e, gs, gw, gws, gbs, gq, ci, cs)
     check(lib().o2m_style_bwd(ptr(sums), ptr(bias), ptr(dots), ptr(s), ptr(d), ptr(q), ptr(w), ptr(ws),
                               ptr(e), ptr(gs), ptr(gw), ptr(gws), ptr(gbs), ptr(gq), B, WD, ci, cip, cop, cs,
                               _stream(s)), "o2m_style_bwd")
+
+
+def wgrad_finalize(acc, gq, w32, grad, co, ci, c):
+    cop, kh, kw, cip = acc.shape
+    check(lib().o2m_wgrad_finalize(ptr(acc), ptr(gq), ptr(w32), ptr(grad), co, ci, kh * kw, cop, cip, c,
+                                   _stream(acc)), "o2m_wgrad_finalize")
 
 
 def modulate_weights(w32, s, out):

@@ -403,6 +403,31 @@ __global__ __launch_bounds__(NT) void modulate_weights_kernel(const float* w32, 
   }
 }
 
+// ---- weight-gradient finalisation ----------------------------------------------------------
+// grad[o][i][kh][kw] += c * ( acc[o][kh][kw][i] + 2 * gq[o][i] * w32[o][kh][kw][i] ), then the
+// accumulators are cleared for the next backward pass.  acc is the kernel-layout fp32 buffer
+// o2m_conv2d_wgrad adds into; the gq term is dL/dQ of the demodulation (Q = sum_k (c W)^2).
+__global__ __launch_bounds__(NT) void wgrad_finalize_kernel(float* acc, float* gq, const float* w32,
+                                                            float* grad, int Co, int Ci, int KK, int Cip,
+                                                            float c, long n) {
+  for (long t = (long)blockIdx.x * NT + threadIdx.x; t < n; t += (long)gridDim.x * NT) {
+    // t indexes the kernel layout [o][kk][i] (reads coalesced; writes scattered but tiny)
+    const int i = (int)(t % Cip);
+    const long r = t / Cip;
+    const int kk = (int)(r % KK);
+    const int o = (int)(r / KK);
+    float v = acc[t];
+    acc[t] = 0.f;
+    if (o < Co && i < Ci) {
+      if (gq) v += 2.f * gq[(size_t)o * Cip + i] * w32[t];
+      grad[((size_t)o * Ci + i) * KK + kk] += c * v;
+    }
+  }
+}
+__global__ void clear_kernel(float* p, long n) {
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) p[t] = 0.f;
+}
+
 // ---- fused Adam ------------------------------------------------------------------------------
 __global__ __launch_bounds__(NT) void adam_kernel(float* p, const float* g, float* m, float* v,
                                                   const float* step, long n, float lr, float b1,
@@ -572,6 +597,22 @@ int o2m_unpack_nhwc(const void* src, float* dst, int32_t B, int32_t C, int32_t H
   DISPATCH_T(dtype, hipLaunchKernelGGL(unpack_kernel<T>, dim3(grid_for(npix)), dim3(NT), 0, s,
                                        (const T*)src, dst, C, H * W, Cp, npix));
   O2M_LAUNCH_CHECK();
+  return 0;
+}
+
+int o2m_wgrad_finalize(float* acc, float* gq, const float* w32, float* grad, int32_t Co, int32_t Ci,
+                       int32_t KK, int32_t Cop, int32_t Cip, float c, void* stream) {
+  if (!acc || !grad || Co <= 0 || Ci <= 0 || KK <= 0 || Cop < Co || Cip < Ci || (gq && !w32))
+    return O2M_ERR_BAD_ARG;
+  const long n = (long)Cop * KK * Cip;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(grid_for(n)), dim3(NT), 0, s, acc, gq, w32, grad, Co, Ci, KK,
+                     Cip, c, n);
+  O2M_LAUNCH_CHECK();
+  if (gq) {
+    hipLaunchKernelGGL(clear_kernel, dim3(grid_for((long)Cop * Cip)), dim3(NT), 0, s, gq, (long)Cop * Cip);
+    O2M_LAUNCH_CHECK();
+  }
   return 0;
 }
 

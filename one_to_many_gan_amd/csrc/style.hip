@@ -7,7 +7,8 @@
 //              gs[b,i] = dots[b,i] + 2 s[b,i] sum_o e[b,o] Q[o,i]
 //              gw[b,j] = cs sum_i gs[b,i] Ws[i,j]
 //              gWs[i,j] = cs sum_b gs[b,i] w[b,j] ;  gbs[i] = sum_b gs[b,i]
-//              gq[o,i]  = sum_b e[b,o] s[b,i]^2        (-> dL/dQ, folded into the weight gradient)
+//              gq[o,i] += sum_b e[b,o] s[b,i]^2        (-> dL/dQ, folded into the weight gradient
+//                                                         by o2m_wgrad_finalize)
 // with S0 = sum_p gu, S1 = sum_p gu*(y-residual) from o2m_act_bwd_reduce and
 // dots = sum_p gxm*x from o2m_fold_scale_dot.
 #include "common.h"
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(NT) void style_bwd_batch_kernel(const float* gs, co
       const float sv = s[(size_t)b * Cip + i];
       a += e[(size_t)b * Cop + o] * sv * sv;
     }
-    gq[(size_t)o * Cip + i] = a;
+    gq[(size_t)o * Cip + i] += a;  // accumulates over the uses of the layer in one backward
   }
 }
 

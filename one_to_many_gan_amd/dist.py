@@ -41,8 +41,12 @@ class BucketReducer:
         self.enabled = True
         optimiser.grad_scale = 1.0 / self.world
         optimiser.pre_step_hooks.append(self.wait)
+        from . import ops
+
         for p in self.bucket.params:
             p.register_post_accumulate_grad_hook(self._on_grad)
+            # conv filters get their gradient from ops._finalize_weight_grads, not AccumulateGrad
+            ops.GRAD_READY_HOOKS[p] = self._on_grad
 
     def _on_grad(self, _param):
         if not self.enabled:

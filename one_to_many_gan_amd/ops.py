@@ -118,6 +118,22 @@ class PreparedWeight:
         self.c = 1.0 / math.sqrt(ci * kh * kw)
         self._key = None
         self._val = None
+        # end-of-backward gradient accumulators (kernel layout), see _finalize_weight_grads
+        self.dw_acc = None
+        self.gq_acc = None
+        self.pending = False
+
+    def accumulators(self, device):
+        if self.dw_acc is None or self.dw_acc.device != device:
+            self.dw_acc = torch.zeros((self.cop, self.kh, self.kw, self.cip), dtype=torch.float32, device=device)
+            self.gq_acc = (torch.zeros((self.cop, self.cip), dtype=torch.float32, device=device)
+                           if self.need_q else None)
+        if not self.pending:
+            self.pending = True
+            if not _PENDING:
+                torch.autograd.Variable._execution_engine.queue_callback(_finalize_weight_grads)
+            _PENDING.append(self)
+        return self.dw_acc, self.gq_acc
 
     def get(self):
         w = self.weight
@@ -132,9 +148,38 @@ class PreparedWeight:
                 w_d = full.flip(1, 2).permute(3, 1, 2, 0).to(compute_dtype()).contiguous()
                 q = full.square().sum(dim=(1, 2)).contiguous() if self.need_q else None
                 qt = q.t().contiguous() if self.need_q else None
-            self._val = (w_f, w_d, q, full if self.need_q else None, qt)
+            self._val = (w_f, w_d, q, full, qt)
             self._key = key
         return self._val
+
+
+_PENDING: list = []
+# parameter -> callable(param), invoked when that filter's gradient has been written by
+# _finalize_weight_grads (the data-parallel reducer counts these like autograd's own
+# post-accumulate hooks, which never fire for the filters)
+GRAD_READY_HOOKS: dict = {}
+
+
+def _finalize_weight_grads():
+    """Runs once at the end of every backward pass (autograd engine callback): converts each
+    touched layer's accumulated kernel-layout weight gradient into ``weight.grad``."""
+    pend = list(_PENDING)
+    _PENDING.clear()
+    for prep in pend:
+        prep.pending = False
+        w = prep.weight
+        if w.grad is None:
+            w.grad = torch.zeros_like(w)
+        grad = w.grad
+        if not grad.is_contiguous() or grad.dtype != torch.float32:
+            tmp = torch.zeros(w.shape, dtype=torch.float32, device=w.device)
+            H.wgrad_finalize(prep.dw_acc, prep.gq_acc, prep.get()[3], tmp, prep.co, prep.ci, prep.c)
+            grad.add_(tmp.to(grad.dtype))
+        else:
+            H.wgrad_finalize(prep.dw_acc, prep.gq_acc, prep.get()[3], grad, prep.co, prep.ci, prep.c)
+        hook = GRAD_READY_HOOKS.get(w)
+        if hook is not None:
+            hook(w)
 
 
 def _pad_cols(t: torch.Tensor, n: int) -> torch.Tensor:
@@ -231,11 +276,12 @@ class _ConvFn(torch.autograd.Function):
             else:
                 g_x = gxp
 
-        g_w = None
+        gq_acc = None
         if need_w:
-            dw = torch.zeros((prep.cop, prep.kh, prep.kw, cip), dtype=torch.float32, device=dev)
-            H.conv2d_wgrad(x, gu, dw, in_scale=s, pad=pad, pad_mode=pad_mode)
-            g_w = dw[: prep.co, :, :, : prep.ci].permute(0, 3, 1, 2) * prep.c
+            # accumulated in the kernel layout across every use of the layer in this backward;
+            # converted into weight.grad once, by _finalize_weight_grads
+            dw_acc, gq_acc = prep.accumulators(dev)
+            H.conv2d_wgrad(x, gu, dw_acc, in_scale=s, pad=pad, pad_mode=pad_mode)
 
         g_ws = g_tw = g_tb = None
         if s is not None and (need_s or (need_w and d is not None)):
@@ -247,16 +293,13 @@ class _ConvFn(torch.autograd.Function):
             g_ws = torch.empty((B, wd_), dtype=torch.float32, device=dev)
             g_tw = torch.empty((prep.ci, wd_), dtype=torch.float32, device=dev)
             g_tb = torch.empty((prep.ci,), dtype=torch.float32, device=dev)
-            gq = torch.empty((prep.cop, cip), dtype=torch.float32, device=dev) if d is not None else None
+            gq = None
+            if d is not None:  # dL/dQ: kept only if the filter wants a gradient
+                gq = gq_acc if gq_acc is not None else torch.zeros((prep.cop, cip), dtype=torch.float32, device=dev)
             H.style_bwd(sums, bias_p, dots, s, d, q, wv, ws, e, gs, g_ws, g_tw, g_tb, gq, prep.ci,
                         1.0 / math.sqrt(wd_))
-            if need_w and gq is not None:
-                # Q = c^2 sum_k W^2  ->  dL/dW += dL/dQ * 2 c^2 W
-                g_w = g_w + gq[: prep.co, : prep.ci, None, None] * (2.0 * prep.c * prep.c) * weight.detach().float()
-        if g_w is not None:
-            g_w = g_w.to(weight.dtype).contiguous()
         g_res = g if (ctx.has_res and need_res) else None
-        return (g_x if need_x else None, g_w, g_bias, g_ws, g_tw, g_tb, g_res,
+        return (g_x if need_x else None, None, g_bias, g_ws, g_tw, g_tb, g_res,
                 None, None, None, None, None, None)
 
 
