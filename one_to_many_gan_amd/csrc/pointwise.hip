@@ -263,11 +263,15 @@ __global__ __launch_bounds__(NT) void in_apply_kernel(const T* x, const T* g,
 }
 
 // ---- separable banded resample -----------------------------------------------------------
-template <typename T>
+// Tap count is a template parameter: the 2*TN weights and the TN*TN input vectors of one output
+// are all loaded up front (independent loads in flight) instead of a dependent
+// weight -> index -> data chain per tap.  Source indices are clamped (taps whose weight is
+// zero may point past the edge).
+template <typename T, int TN>
 __global__ __launch_bounds__(NT) void resample_kernel(const T* x, T* y, const int* sy,
                                                       const float* wy, const int* sx,
                                                       const float* wx, int H, int W, int Ho,
-                                                      int Wo, int C, int Tn, long nvec) {
+                                                      int Wo, int C, long nvec) {
   const int CV = C / 8;
   for (long v = (long)blockIdx.x * NT + threadIdx.x; v < nvec; v += (long)gridDim.x * NT) {
     const int cv = (int)(v % CV);
@@ -276,22 +280,29 @@ __global__ __launch_bounds__(NT) void resample_kernel(const T* x, T* y, const in
     const int oy = (int)(r % Ho);
     const int b = (int)(r / Ho);
     const int y0 = sy[oy], x0 = sx[ox];
+    float a[TN], c[TN];
+#pragma unroll
+    for (int t = 0; t < TN; ++t) { a[t] = wy[oy * TN + t]; c[t] = wx[ox * TN + t]; }
+    const T* base = x + ((size_t)b * H * W) * C + cv * 8;
     float acc[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-    for (int ty = 0; ty < Tn; ++ty) {
-      const float a = wy[oy * Tn + ty];
-      const int iy = y0 + ty;
-      if (a == 0.f || iy >= H) continue;
-      for (int tx = 0; tx < Tn; ++tx) {
-        const float wgt = a * wx[ox * Tn + tx];
-        const int ix = x0 + tx;
-        if (wgt == 0.f || ix >= W) continue;
-        float t[8];
-        load8(x + (((size_t)b * H + iy) * W + ix) * C + cv * 8, t);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] += wgt * t[i];
+    for (int ty = 0; ty < TN; ++ty) {
+      const int iy = min(y0 + ty, H - 1);
+      float row[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) row[i] = 0.f;
+#pragma unroll
+      for (int tx = 0; tx < TN; ++tx) {
+        const int ix = min(x0 + tx, W - 1);
+        float t[8];
+        load8(base + ((size_t)iy * W + ix) * C, t);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) row[i] += c[tx] * t[i];
       }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] += a[ty] * row[i];
     }
     store8(y + (size_t)v * 8, acc);
   }
@@ -572,8 +583,17 @@ int o2m_resample2d(const void* x, void* y, const int32_t* sy, const float* wy, c
     return O2M_ERR_BAD_ARG;
   const long nvec = (long)B * Ho * Wo * (C / 8);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(resample_kernel<T>, dim3(grid_for(nvec)), dim3(NT), 0, s,
-                                       (const T*)x, (T*)y, sy, wy, sx, wx, H, W, Ho, Wo, C, T_, nvec));
+#define O2M_RESAMPLE_CASE(TN)                                                                   \
+  case TN:                                                                                       \
+    DISPATCH_T(dtype, hipLaunchKernelGGL((resample_kernel<T, TN>), dim3(grid_for(nvec)), dim3(NT), 0, s, \
+                                         (const T*)x, (T*)y, sy, wy, sx, wx, H, W, Ho, Wo, C, nvec)); \
+    break;
+  switch (T_) {
+    O2M_RESAMPLE_CASE(1) O2M_RESAMPLE_CASE(2) O2M_RESAMPLE_CASE(3) O2M_RESAMPLE_CASE(4)
+    O2M_RESAMPLE_CASE(5) O2M_RESAMPLE_CASE(6) O2M_RESAMPLE_CASE(7) O2M_RESAMPLE_CASE(8)
+    default: return O2M_ERR_UNSUPPORTED;
+  }
+#undef O2M_RESAMPLE_CASE
   O2M_LAUNCH_CHECK();
   return 0;
 }
