@@ -13,7 +13,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libo2m_hip.so")
+# O2M_HIP_LIB: alternative build of the same ABI (kernel A/B experiments only)
+LIB_PATH = os.environ.get("O2M_HIP_LIB") or os.path.join(_HERE, "lib", "libo2m_hip.so")
 
 BF16, F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3

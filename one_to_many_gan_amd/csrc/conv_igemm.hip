@@ -97,6 +97,9 @@ __device__ __forceinline__ void stg_to_lds(const Stg<T>& s, const f32x4 (&sc)[2]
   }
 }
 
+// 16 zero bytes in global memory: the LDS-DMA source of every padding / out-of-problem slot
+__device__ __attribute__((aligned(16))) unsigned int o2m_zero16[4] = {0u, 0u, 0u, 0u};
+
 // WIDE: Ci % 64 == 0, so one 64-element stage lies inside ONE filter tap (tap-outer walk).
 // !WIDE: small Ci (image stems, Ci = 8..32): every 16-B chunk decodes its own tap.
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool IN_SCALE, bool WIDE>
@@ -112,6 +115,21 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
   constexpr int STAGE_BYTES = NPLANE * (A_BYTES + B_BYTES);
   static_assert(BM % RSTEP == 0 && WM % 32 == 0 && WN % 32 == 0, "tile shape");
+  // LDS-DMA staging (global_load_lds_dwordx4): the tile goes L2 -> LDS without staging VGPRs
+  // and without ds_write.  One wave-instruction fills 64 consecutive 16-B slots (8 rows x 8
+  // chunks); the XOR swizzle is applied on the SOURCE side: lane l of fill q owns linear slot
+  // 64q + l and fetches the (row, chunk) that tile_off maps there.  Needs untransformed data:
+  // plain bf16, no in_scale, stage inside one tap.
+  constexpr bool DMA = !F32 && !IN_SCALE && WIDE && (BN % RSTEP == 0);
+  // Every wave issues its share of the fills.  (Tried and measured slower on the 256->256
+  // layer, 877 TF/s as is: fills dealt out between the k-steps' MFMAs 803; fills issued by
+  // half the waves while their SIMD partners multiply 837; s_setprio around the MFMAs 806.
+  // s_memtime stamps of a stage: ~1020 cycles issuing 8 fills, ~1520 multiplying, ~1200 at the
+  // barrier behind the SIMD partner.)
+  constexpr int NW = WAVES_M * WAVES_N;
+  constexpr int LW = NW;                       // loader waves
+  constexpr int FA = DMA ? RA * NW / LW : RA;  // A fills per loader wave
+  constexpr int FB = DMA ? RB * NW / LW : RB;  // B fills per loader wave
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -144,10 +162,21 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
   // ---- per-thread row bookkeeping for the A gather ---------------------------------
   // pix[j] = linear pixel index (b*H + oy)*W + ox of output pixel (b,oy,ox) taken in the INPUT
   // grid (-1: row outside M); ryx[j] = oy << 16 | ox.
-  int pix[RA], ryx[RA];
+  // DMA mode: fill q covers tile rows 8q .. 8q+7; lane l owns linear slot 64q + l
+  const int dwave = tid >> 6, dlane = tid & 63;
+  auto dma_row = [&](int q) {  // tile row of this lane's slot in fill q
+    const int pr = 4 * q + (dlane >> 4);
+    return 2 * pr + ((((dlane & 15) ^ (pr & 15))) >> 3);
+  };
+  auto dma_chk = [&](int q) {
+    const int pr = 4 * q + (dlane >> 4);
+    return ((dlane & 15) ^ (pr & 15)) & 7;
+  };
+  const bool loader = !DMA || dwave < LW;  // wave-uniform
+  int pix[FA], ryx[FA];
 #pragma unroll
-  for (int j = 0; j < RA; ++j) {
-    const int m = m0 + r0 + RSTEP * j;
+  for (int j = 0; j < FA; ++j) {
+    const int m = m0 + (DMA ? dma_row((dwave % LW) * FA + j) : r0 + RSTEP * j);
     if (m < M) {
       const int b = m / HoWo, rem = m - b * HoWo;
       const int oy = rem / Wo, ox = rem - oy * Wo;
@@ -173,13 +202,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
 
   // tap-outer walk state (WIDE): element offset of (row, tap), or -1 when the tap falls in
   // the zero padding / the row is outside M
-  unsigned aoff[RA];  // byte offsets
+  unsigned aoff[FA];  // byte offsets
   int cur_tap = -1;   // uniform
 
   auto set_tap = [&](int tap) {
     const int dy = tap / KW - pad, dx = tap - (tap / KW) * KW - pad;  // scalar
 #pragma unroll
-    for (int j = 0; j < RA; ++j) {
+    for (int j = 0; j < FA; ++j) {
       const int oy = ryx[j] >> 16, ox = ryx[j] & 0xffff;
       int iy = oy + dy, ix = ox + dx;
       bool ok = pix[j] >= 0;
@@ -189,7 +218,44 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
       } else {
         ok = ok && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
       }
-      aoff[j] = ok ? (unsigned)((pix[j] + (iy - oy) * W + (ix - ox)) * Ci + cc * 8) * ES : OOB_OFF;
+      const int chk = DMA ? dma_chk((dwave % LW) * FA + j) : cc;
+      aoff[j] = ok ? (unsigned)((pix[j] + (iy - oy) * W + (ix - ox)) * Ci + chk * 8) * ES : OOB_OFF;
+    }
+  };
+
+  // DMA mode: element offsets of this lane's filter rows (or -1)
+  int dwoff[FB];
+#pragma unroll
+  for (int j = 0; j < FB; ++j) {
+    const int q = (dwave % LW) * FB + j;
+    const int n = n0 + dma_row(q);
+    dwoff[j] = (DMA && n < Co) ? n * K + dma_chk(q) * 8 : -1;
+  }
+  const unsigned short* Xg = static_cast<const unsigned short*>(d.x);
+  const unsigned short* Wg = static_cast<const unsigned short*>(d.w) + (size_t)b_first * d.w_batch_stride;
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef __attribute__((address_space(1))) const void gbl_void;
+
+  auto dma_tiles = [&](int kt, int stage) {
+    if (!loader) return;
+    const int k0 = kt * BK;
+    const int tap = k0 / Ci;
+    const int cbase = k0 - tap * Ci;
+    if (tap != cur_tap) { set_tap(tap); cur_tap = tap; }
+    char* a_dst = smem + stage * STAGE_BYTES + dwave * FA * 1024;
+    char* b_dst = smem + stage * STAGE_BYTES + A_BYTES + dwave * FB * 1024;
+#pragma unroll
+    for (int j = 0; j < FA; ++j) {
+      const void* src = aoff[j] != OOB_OFF
+                            ? static_cast<const void*>(reinterpret_cast<const char*>(Xg) + aoff[j] + (unsigned)cbase * 2)
+                            : static_cast<const void*>(o2m_zero16);
+      __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(a_dst + j * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < FB; ++j) {
+      const void* src = dwoff[j] >= 0 ? static_cast<const void*>(Wg + dwoff[j] + k0)
+                                      : static_cast<const void*>(o2m_zero16);
+      __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(b_dst + j * 1024), 16, 0, 0);
     }
   };
 
@@ -316,24 +382,34 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
           }
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
-      // keep the fragment registers of ONE k-step live at a time (the big tiles sit at the
-      // 256-VGPR limit; the second wave of the SIMD covers the ds_read latency)
-      if constexpr (TM * TN >= 8) __builtin_amdgcn_sched_barrier(0);
     }
   };
 
   // ---- main loop: issue-early / write-late register staging --------------------------
-  load_tiles(0);
-  store_tiles(0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = NSTAGE == 2 ? (kt & 1) : 0;
-    const bool more = kt + 1 < nk;
-    if (more) load_tiles(kt + 1);
-    compute(cur);
-    if constexpr (NSTAGE == 1) __syncthreads();
-    if (more) store_tiles(NSTAGE == 2 ? (cur ^ 1) : 0);
+  if constexpr (DMA) {
+    dma_tiles(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < nk) dma_tiles(kt + 1, cur ^ 1);  // lands while this stage is multiplied
+      compute(cur);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  } else {
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = NSTAGE == 2 ? (kt & 1) : 0;
+      const bool more = kt + 1 < nk;
+      if (more) load_tiles(kt + 1);
+      compute(cur);
+      if constexpr (NSTAGE == 1) __syncthreads();
+      if (more) store_tiles(NSTAGE == 2 ? (cur ^ 1) : 0);
+      __syncthreads();
+    }
   }
 
   // ---- epilogue -----------------------------------------------------------------------
