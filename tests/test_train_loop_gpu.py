@@ -1,0 +1,43 @@
+"""GPU test of the training loop plumbing: train.run on synthetic data at BASELINE config #1's
+shape (64x64x1, batch 4), checkpoint written with the reference's dictionary keys, resume."""
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_train_loop_checkpoint_and_resume(tmp_path):
+    import train
+    import one_to_many_gan_amd as o2m
+    from tests.cases import make_config
+
+    o2m.set_precision("bf16")
+    cfg = make_config(1, (64, 64), 4)
+    cfg["training"].update(checkpoint_directory=tmp_path, training_run="t", training_steps=3)
+    cfg["evaluation"] = {"log_interval": 2, "checkpoint_interval": 2, "n_evaluation_images": 0,
+                         "inference_batch_size": 4}
+    dev = torch.device("cuda:0")
+    lines = []
+    nets, opts = train.run(cfg, dev, 3, train.synthetic_batches(1, cfg, dev), train.synthetic_batches(2, cfg, dev),
+                           log=lines.append)
+    assert any(l.startswith("[2/3]") for l in lines) and any(l.startswith("[3/3]") for l in lines)
+    ck = tmp_path / "t" / "models" / "3.tar"
+    assert ck.exists() and (tmp_path / "t" / "models" / "2.tar").exists()
+    blob = torch.load(ck, map_location="cpu", weights_only=True)
+    for key in ("generator_state_dict", "discriminator_state_dict", "mapping_network_state_dict",
+                "style_extractor_state_dict", "generator_optimiser_state_dict", "ada_p", "image_buffer",
+                "image_buffer_size"):
+        assert key in blob, key
+    assert len(blob["image_buffer"]) == 12  # 3 steps x batch 4 generated images pooled
+    # resume continues from step 3 with identical weights and Adam state
+    lines2 = []
+    nets2, opts2 = train.run(cfg, dev, 4, train.synthetic_batches(1, cfg, dev), train.synthetic_batches(2, cfg, dev),
+                             resume=ck, log=lines2.append)
+    assert lines2[0].endswith("at step 3")
+    assert float(opts2["G"].step_t) == 4.0
+    # the oracle's modules load the same checkpoint (reference key layout)
+    from oracle import model as om
+
+    g = om.Generator(1, 6, (64, 64), 64, 7)
+    g.load_state_dict(blob["generator_state_dict"])
