@@ -18,10 +18,14 @@ namespace {
 constexpr int NT = 256;
 constexpr int MAXWD = 16;
 
+// grid (B, ceil(Cop/64)): every block recomputes the (cheap) style vector of its sample into
+// LDS; its 256 threads then cover 64 output channels x 4 slices of the reduction over i.
 __global__ __launch_bounds__(NT) void style_fwd_kernel(const float* w, const float* Ws, const float* bs,
                                                        const float* Qt, float* s, float* d, int WD,
                                                        int Ci, int Cip, int Cop, float cs, float eps) {
-  extern __shared__ float s2[];  // [Cip]
+  extern __shared__ float sm[];  // s2[Cip] then part[4][64]
+  float* s2 = sm;
+  float* part = sm + Cip;
   const int b = blockIdx.x;
   float wv[MAXWD];
 #pragma unroll
@@ -32,25 +36,32 @@ __global__ __launch_bounds__(NT) void style_fwd_kernel(const float* w, const flo
       for (int j = 0; j < WD; ++j) v += wv[j] * Ws[(size_t)i * WD + j];
       v = v * cs + bs[i];
     }
-    s[(size_t)b * Cip + i] = v;
+    if (blockIdx.y == 0) s[(size_t)b * Cip + i] = v;
     s2[i] = v * v;
   }
   if (!d) return;
   __syncthreads();
-  for (int o = threadIdx.x; o < Cop; o += NT) {
-    float a = eps;
-    for (int i = 0; i < Cip; ++i) a += Qt[(size_t)i * Cop + o] * s2[i];  // lanes over o: coalesced
-    d[(size_t)b * Cop + o] = rsqrtf(a);
-  }
+  const int ol = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int o = blockIdx.y * 64 + ol;
+  const int per = (Cip + 3) / 4, i0 = sl * per, i1 = min(Cip, i0 + per);
+  float a = 0.f;
+  if (o < Cop)
+    for (int i = i0; i < i1; ++i) a += Qt[(size_t)i * Cop + o] * s2[i];  // lanes over o: coalesced
+  part[sl * 64 + ol] = a;
+  __syncthreads();
+  if (sl == 0 && o < Cop)
+    d[(size_t)b * Cop + o] = rsqrtf(eps + part[ol] + part[64 + ol] + part[128 + ol] + part[192 + ol]);
 }
 
-// per sample: e, gs, gw
+// grid (B, ceil(Cip/64)): e (recomputed per block into LDS), then 64 input channels x 4 slices
+// of the reduction over o; gw is accumulated with atomics (zeroed by the caller).
 __global__ __launch_bounds__(NT) void style_bwd_sample_kernel(
     const float* sums, const float* bias, const float* dots, const float* s, const float* d, const float* Q,
     const float* Ws, float* e, float* gs, float* gw, int WD, int Ci, int Cip, int Cop, float cs) {
-  extern __shared__ float sm[];  // e[Cop] then per-wave partials
+  extern __shared__ float sm[];  // es[Cop], part[4][64], gsl[64]
   float* es = sm;
-  float* part = sm + Cop;  // [NT/64][MAXWD]
+  float* part = sm + Cop;
+  float* gsl = part + 256;
   const int b = blockIdx.x;
   if (d) {
     for (int o = threadIdx.x; o < Cop; o += NT) {
@@ -58,35 +69,36 @@ __global__ __launch_bounds__(NT) void style_bwd_sample_kernel(
       const float dd = d[(size_t)b * Cop + o];
       const float ev = -0.5f * dd * dd * (s1 - (bias ? bias[o] * s0 : 0.f));
       es[o] = ev;
-      e[(size_t)b * Cop + o] = ev;
+      if (blockIdx.y == 0) e[(size_t)b * Cop + o] = ev;
     }
   }
   __syncthreads();
-  float acc[MAXWD];
-#pragma unroll
-  for (int j = 0; j < MAXWD; ++j) acc[j] = 0.f;
-  for (int i = threadIdx.x; i < Cip; i += NT) {
-    float g = dots[(size_t)b * Cip + i];
-    if (d) {
-      float t = 0.f;
-      for (int o = 0; o < Cop; ++o) t += es[o] * Q[(size_t)o * Cip + i];  // lanes over i: coalesced
-      g += 2.f * s[(size_t)b * Cip + i] * t;
-    }
-    if (i >= Ci) g = 0.f;
-    gs[(size_t)b * Cip + i] = g;
-    if (i < Ci)
-      for (int j = 0; j < WD; ++j) acc[j] += g * Ws[(size_t)i * WD + j];
+  const int il = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int i = blockIdx.y * 64 + il;
+  float t = 0.f;
+  if (d && i < Cip) {
+    const int per = (Cop + 3) / 4, o0 = sl * per, o1 = min(Cop, o0 + per);
+    for (int o = o0; o < o1; ++o) t += es[o] * Q[(size_t)o * Cip + i];  // lanes over i: coalesced
   }
-#pragma unroll
-  for (int j = 0; j < MAXWD; ++j) acc[j] = wave_sum(acc[j]);
-  if ((threadIdx.x & 63) == 0)
-#pragma unroll
-    for (int j = 0; j < MAXWD; ++j) part[(threadIdx.x >> 6) * MAXWD + j] = acc[j];
+  part[sl * 64 + il] = t;
   __syncthreads();
-  if (threadIdx.x < WD) {
-    float t = 0.f;
-    for (int wv = 0; wv < NT / 64; ++wv) t += part[wv * MAXWD + threadIdx.x];
-    gw[(size_t)b * WD + threadIdx.x] = t * cs;
+  if (sl == 0) {
+    float g = 0.f;
+    if (i < Ci) {
+      g = dots[(size_t)b * Cip + i];
+      if (d) g += 2.f * s[(size_t)b * Cip + i] * (part[il] + part[64 + il] + part[128 + il] + part[192 + il]);
+    }
+    if (i < Cip) gs[(size_t)b * Cip + i] = g;
+    gsl[il] = g;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < WD) {  // gw[b][j] += cs * sum_i gs[i] Ws[i][j] over this block's 64 channels
+    float a = 0.f;
+    for (int q = 0; q < 64; ++q) {
+      const int ii = blockIdx.y * 64 + q;
+      if (ii < Ci) a += gsl[q] * Ws[(size_t)ii * WD + threadIdx.x];
+    }
+    atomicAdd(gw + (size_t)b * WD + threadIdx.x, a * cs);
   }
 }
 
@@ -131,8 +143,8 @@ int o2m_style_fwd(const float* w, const float* Ws, const float* bs, const float*
                   void* stream) {
   if (!w || !Ws || !bs || !s || B <= 0 || WD <= 0 || WD > MAXWD || Ci <= 0 || Cip < Ci) return O2M_ERR_BAD_ARG;
   if (d && (!Qt || Cop <= 0)) return O2M_ERR_BAD_ARG;
-  hipLaunchKernelGGL(style_fwd_kernel, dim3(B), dim3(NT), Cip * sizeof(float), static_cast<hipStream_t>(stream),
-                     w, Ws, bs, Qt, s, d, WD, Ci, Cip, Cop, cs, eps);
+  hipLaunchKernelGGL(style_fwd_kernel, dim3(B, d ? (Cop + 63) / 64 : 1), dim3(NT), (Cip + 256) * sizeof(float),
+                     static_cast<hipStream_t>(stream), w, Ws, bs, Qt, s, d, WD, Ci, Cip, Cop, cs, eps);
   O2M_LAUNCH_CHECK();
   return 0;
 }
@@ -145,9 +157,10 @@ int o2m_style_bwd(const float* sums, const float* bias, const float* dots, const
   if (B <= 0 || WD <= 0 || WD > MAXWD || Ci <= 0 || Cip < Ci || Cop <= 0) return O2M_ERR_BAD_ARG;
   if (d && (!sums || !Q || !e || !gq)) return O2M_ERR_BAD_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const size_t lds = (Cop + (NT / 64) * MAXWD) * sizeof(float);
-  hipLaunchKernelGGL(style_bwd_sample_kernel, dim3(B), dim3(NT), lds, st, sums, bias, dots, s, d, Q, Ws, e, gs,
-                     gw, WD, Ci, Cip, Cop, cs);
+  const size_t lds = (Cop + 256 + 64) * sizeof(float);
+  (void)hipMemsetAsync(gw, 0, (size_t)B * WD * sizeof(float), st);
+  hipLaunchKernelGGL(style_bwd_sample_kernel, dim3(B, (Cip + 63) / 64), dim3(NT), lds, st, sums, bias, dots, s, d,
+                     Q, Ws, e, gs, gw, WD, Ci, Cip, Cop, cs);
   O2M_LAUNCH_CHECK();
   const int pb = (Ci + NT - 1) / NT;
   hipLaunchKernelGGL(style_bwd_batch_kernel, dim3(pb + (d ? Cop : 0)), dim3(NT), 0, st, gs, w, e, s, gWs, gbs,

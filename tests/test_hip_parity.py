@@ -110,7 +110,10 @@ def test_training_steps_match_reference(name, precision, golden_dir):
     # step 0 depends on the forward only; step 1 and the probes also on one Adam update of
     # every parameter by ~lr*sign(g) -- sign flips of tiny gradients perturb them slightly
     # (bf16: gradient noise flips the sign of ~1/6 of the +-lr Adam moves, see the yardstick)
-    loose = {"fp32": 2e-2, "bf16": 2e-1}[precision]
+    # Adam's first update is lr*sign(g): every weight whose |g| lies below the gradient noise
+    # floor (ReLU-mask flips already put ~1e-2 of relative noise on encoder gradients in fp32
+    # mode) moves by +-2 lr, whatever the precision
+    loose = {"fp32": 5e-2, "bf16": 2e-1}[precision]
     tight = {"fp32": 2e-3, "bf16": 5e-2}[precision]
     bad = []
     for k in gold.files:
