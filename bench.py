@@ -184,6 +184,7 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--dump-params", default=None, help="write a checksum of every rank's weights (tests)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -191,11 +192,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    device = torch.device("cuda", local_rank)
+    # O2M_DIST_BACKEND=gloo + O2M_SHARE_GPU=1: rehearsal of the multi-rank path on ONE GPU
+    # (tests/test_dist_gpu.py); the real runs use RCCL ("nccl") with one GPU per rank.
+    backend = os.environ.get("O2M_DIST_BACKEND", "nccl")
+    share = os.environ.get("O2M_SHARE_GPU") == "1"
+    device = torch.device("cuda", 0 if share else local_rank)
     torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     cfg = make_config(args.size, args.channels, args.batch)
     trainer = Trainer(product_namespace(args.precision), cfg, device, seed_offset=rank)
@@ -251,6 +259,10 @@ def main():
         out["roofline"] = kernel_profile(trainer, args.precision)
     if world > 1:
         dist.barrier()
+    if args.dump_params:
+        sums = [float(o.bucket.flat.double().sum()) for o in (trainer.oD, trainer.oG, trainer.oM, trainer.oS)]
+        with open(f"{args.dump_params}.rank{rank}", "w") as f:
+            json.dump(sums, f)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.size, args.channels)
     if rank == 0:

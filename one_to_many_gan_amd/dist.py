@@ -33,6 +33,7 @@ class BucketReducer:
         self.pending = len(self.bucket.params)
         self.left = self.pending
         self.launched = False
+        self.seen = set()
         self.work = None
         dev = self.bucket.flat.device
         self.on_gpu = dev.type == "cuda"
@@ -44,13 +45,18 @@ class BucketReducer:
         from . import ops
 
         for p in self.bucket.params:
-            p.register_post_accumulate_grad_hook(self._on_grad)
-            # conv filters get their gradient from ops._finalize_weight_grads, not AccumulateGrad
-            ops.GRAD_READY_HOOKS[p] = self._on_grad
+            if p.dim() == 4:
+                # conv filters: their gradient is written by ops._finalize_weight_grads at the end
+                # of backward (kernel-layout accumulators), not by autograd's AccumulateGrad --
+                # whose post-accumulate hook can still fire for them, earlier, and must not count
+                ops.GRAD_READY_HOOKS[p] = self._on_grad
+            else:
+                p.register_post_accumulate_grad_hook(self._on_grad)
 
-    def _on_grad(self, _param):
-        if not self.enabled:
+    def _on_grad(self, param):
+        if not self.enabled or id(param) in self.seen:
             return
+        self.seen.add(id(param))
         self.left -= 1
         if self.left == 0:
             self._launch()
@@ -83,6 +89,7 @@ class BucketReducer:
             self.work = None
         self.left = self.pending
         self.launched = False
+        self.seen.clear()
 
 
 def broadcast_parameters(optimisers, src: int = 0, group=None):
