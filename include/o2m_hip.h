@@ -61,7 +61,7 @@ int o2m_abi_version(void);
  * pad_mode, and the activation behind it (builder.py:196,204,270,301).  The same entry
  * computes the data gradient ("convT2d") when given the flipped/transposed filter and
  * pad' = K-1-pad.
- * Ho = H + 2*pad - KH + 1 (likewise Wo).  Ci % 8 == 0, Co % 8 == 0.
+ * Ho = (H + 2*pad - KH)/stride + 1 (likewise Wo).  Ci % 8 == 0, Co % 8 == 0.
  * w layout: [Co][KH][KW][Ci] (reduction index contiguous), element type `dtype`.
  */
 typedef struct {
@@ -76,7 +76,10 @@ typedef struct {
   int32_t w_batch_stride; /* 0: one filter for all samples.  >0: sample b uses w + b*stride
                              elements (pre-modulated per-sample filters, o2m_modulate_weights);
                              requires Ho*Wo % 256 == 0 so no MFMA tile straddles samples */
-  int32_t reserved[4];
+  int32_t stride;         /* 0 or 1: stride 1; s > 1: Ho = (H + 2*pad - KH)/s + 1.  Used by the host
+                             for the space-to-depth form of the N = 3 image conv (a 7x7 stride-1
+                             conv with 3 outputs = a 10x10 stride-4 conv with 48 outputs) */
+  int32_t reserved[3];
 } o2m_conv_desc;
 int o2m_conv2d_fwd(const o2m_conv_desc* d, void* stream);
 

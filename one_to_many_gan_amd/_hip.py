@@ -30,7 +30,7 @@ class ConvDesc(C.Structure):
                 ("bias", _vp), ("residual", _vp),
                 ("B", _i32), ("H", _i32), ("W", _i32), ("Ci", _i32), ("Co", _i32), ("KH", _i32),
                 ("KW", _i32), ("pad", _i32), ("pad_mode", _i32), ("act", _i32), ("dtype", _i32),
-                ("w_batch_stride", _i32), ("reserved", _i32 * 4)]
+                ("w_batch_stride", _i32), ("stride", _i32), ("reserved", _i32 * 3)]
 
 
 class WgradDesc(C.Structure):
@@ -146,12 +146,12 @@ def check(err: int, what: str):
 
 
 def conv2d_fwd(x, w, y, *, in_scale=None, out_scale=None, bias=None, residual=None, pad, pad_mode, act,
-               per_sample_w=False):
+               per_sample_w=False, stride=1):
     B, H, W, Ci = x.shape
     Co, KH, KW, _ = w.shape[-4:]
-    stride = Co * KH * KW * Ci if per_sample_w else 0
+    wstride = Co * KH * KW * Ci if per_sample_w else 0
     d = ConvDesc(ptr(x), ptr(w), ptr(y), ptr(in_scale), ptr(out_scale), ptr(bias), ptr(residual),
-                 B, H, W, Ci, Co, KH, KW, pad, pad_mode, act, dtype_code(x.dtype), stride)
+                 B, H, W, Ci, Co, KH, KW, pad, pad_mode, act, dtype_code(x.dtype), wstride, stride)
     flops = 2.0 * y.shape[0] * y.shape[1] * y.shape[2] * Co * KH * KW * Ci
     _timed(_igemm_name(x.dtype, Co, in_scale is not None), flops, x,
            lambda: check(lib().o2m_conv2d_fwd(C.byref(d), _stream(x)), "o2m_conv2d_fwd"))

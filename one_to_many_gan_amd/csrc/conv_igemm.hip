@@ -135,7 +135,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
 
   constexpr int ES = sizeof(T);  // element size in bytes
   const int H = d.H, W = d.W, Ci = d.Ci, Co = d.Co, KH = d.KH, KW = d.KW, pad = d.pad;
-  const int Ho = H + 2 * pad - KH + 1, Wo = W + 2 * pad - KW + 1;
+  const int S = d.stride > 1 ? d.stride : 1;
+  const int Ho = (H + 2 * pad - KH) / S + 1, Wo = (W + 2 * pad - KW) / S + 1;
   const int HoWo = Ho * Wo;
   const int M = d.B * HoWo;
   const int K = KH * KW * Ci;
@@ -160,8 +161,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
   const int r0 = tid >> 3;  // 0 .. RSTEP-1
 
   // ---- per-thread row bookkeeping for the A gather ---------------------------------
-  // pix[j] = linear pixel index (b*H + oy)*W + ox of output pixel (b,oy,ox) taken in the INPUT
-  // grid (-1: row outside M); ryx[j] = oy << 16 | ox.
+  // pix[j] = linear index (b*H + oy*S)*W + ox*S of the input pixel under output pixel (b,oy,ox)
+  // (-1: row outside M); ryx[j] = oy*S << 16 | ox*S.
   // DMA mode: fill q covers tile rows 8q .. 8q+7; lane l owns linear slot 64q + l
   const int dwave = tid >> 6, dlane = tid & 63;
   auto dma_row = [&](int q) {  // tile row of this lane's slot in fill q
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
     const int m = m0 + (DMA ? dma_row((dwave % LW) * FA + j) : r0 + RSTEP * j);
     if (m < M) {
       const int b = m / HoWo, rem = m - b * HoWo;
-      const int oy = rem / Wo, ox = rem - oy * Wo;
+      const int oy = (rem / Wo) * S, ox = (rem - (rem / Wo) * Wo) * S;
       pix[j] = (b * H + oy) * W + ox;
       ryx[j] = (oy << 16) | ox;
     } else {
@@ -483,7 +484,8 @@ constexpr int lds_bytes() {
 
 template <int BM, int BN>
 long tiles_for(const o2m_conv_desc& d) {
-  const int Ho = d.H + 2 * d.pad - d.KH + 1, Wo = d.W + 2 * d.pad - d.KW + 1;
+  const int S = d.stride > 1 ? d.stride : 1;
+  const int Ho = (d.H + 2 * d.pad - d.KH) / S + 1, Wo = (d.W + 2 * d.pad - d.KW) / S + 1;
   const long M = (long)d.B * Ho * Wo;
   return ((M + BM - 1) / BM) * ((d.Co + BN - 1) / BN);
 }
@@ -546,7 +548,9 @@ extern "C" int o2m_conv2d_fwd(const o2m_conv_desc* d, void* stream) {
   if ((long)d->B * d->H * d->W * (long)d->Ci * esz > 0x7fffffffL) return O2M_ERR_UNSUPPORTED;
   if (d->w_batch_stride < 0) return O2M_ERR_BAD_ARG;
   if ((long)d->Co * d->KH * d->KW * (long)d->Ci * esz > 0x7fffffffL) return O2M_ERR_UNSUPPORTED;
+  if (d->stride < 0 || d->stride > 16) return O2M_ERR_BAD_ARG;
   if (d->w_batch_stride > 0) {
+    if (d->stride > 1) return O2M_ERR_BAD_ARG;
     const long howo = (long)(d->H + 2 * d->pad - d->KH + 1) * (d->W + 2 * d->pad - d->KW + 1);
     if (howo % 256 != 0 || d->in_scale) return O2M_ERR_BAD_ARG;
   }

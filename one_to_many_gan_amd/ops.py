@@ -135,6 +135,31 @@ class PreparedWeight:
             _PENDING.append(self)
         return self.dw_acc, self.gq_acc
 
+    S2D = 4  # output pixels per side folded into channels by the space-to-depth form
+
+    def s2d_ok(self, pad, pad_mode, hh, ww):
+        """The few-output image conv (Co <= 8, large kernel) as a strided conv over 4x4 output
+        blocks: out[4by+dy, 4bx+dx, co] = sum W[co, kh-dy, kw-dx] x[4by+kh-pad, 4bx+kw-pad]."""
+        r = self.S2D
+        return (self.cop == 8 and self.kh >= 5 and self.kh == self.kw and 2 * pad == self.kh - 1
+                and pad_mode == H.PAD_REFLECT and hh % r == 0 and ww % r == 0 and self.ci % 64 == 0)
+
+    def s2d_weights(self):
+        key = (self.weight._version, self.weight.data_ptr(), _STATE["epoch"], compute_dtype())
+        if getattr(self, "_s2d_key", None) != key:
+            full = self.get()[3]  # [cop, kh, kw, cip] fp32, W*c
+            r, k = self.S2D, self.kh
+            kk = k + r - 1
+            nco = pad8(r * r * self.co)
+            w2 = torch.zeros((nco, kk, kk, self.cip), dtype=torch.float32, device=full.device)
+            for dy in range(r):
+                for dx in range(r):
+                    o0 = (dy * r + dx) * self.co
+                    w2[o0: o0 + self.co, dy: dy + k, dx: dx + k, :] = full[: self.co]
+            self._s2d_val = w2.to(compute_dtype()).contiguous()
+            self._s2d_key = key
+        return self._s2d_val
+
     def get(self):
         w = self.weight
         key = (w._version, w.data_ptr(), _STATE["epoch"], compute_dtype())
@@ -219,7 +244,20 @@ class _ConvFn(torch.autograd.Function):
             bias_p = torch.zeros(prep.cop, dtype=torch.float32, device=x.device)
             bias_p[: prep.co] = bias.detach().float()
         y = torch.empty((B, ho, wo, prep.cop), dtype=x.dtype, device=x.device)
-        if s is not None and (ho * wo) % 256 == 0:
+        if s is None and residual is None and prep.s2d_ok(pad, pad_mode, Hh, Ww):
+            # image conv with 3 (1) real outputs: 4x4 output pixels per GEMM row
+            r = prep.S2D
+            w2 = prep.s2d_weights()
+            b2 = None
+            if bias_p is not None:
+                b2 = torch.zeros(w2.shape[0], dtype=torch.float32, device=x.device)
+                b2[: r * r * prep.co] = bias_p[: prep.co].repeat(r * r)
+            y2 = torch.empty((B, Hh // r, Ww // r, w2.shape[0]), dtype=x.dtype, device=x.device)
+            H.conv2d_fwd(x, w2, y2, bias=b2, pad=pad, pad_mode=pad_mode, act=act, stride=r)
+            y.zero_()
+            y.view(B, Hh // r, r, Ww // r, r, prep.cop)[..., : prep.co] = (
+                y2[..., : r * r * prep.co].view(B, Hh // r, Ww // r, r, r, prep.co).permute(0, 1, 3, 2, 4, 5))
+        elif s is not None and (ho * wo) % 256 == 0:
             # style folded into per-sample filters (rounded after folding): the A-operand
             # loader stays a plain copy, like the unmodulated conv
             w_b = torch.empty((B, *w_f.shape), dtype=x.dtype, device=x.device)

@@ -347,6 +347,7 @@ _reg("conv4_p1", case_conv, cin=8, cout=8, k=4, pad=1, bias=True, n=2, h=13, w=1
 _reg("conv4_rgb", case_conv, cin=3, cout=16, k=4, pad=1, bias=True, n=2, h=17, w=16)
 _reg("conv7_reflect_rgb", case_conv, cin=3, cout=8, k=7, pad=0, bias=True, n=2, h=12, w=14, reflect=3)
 _reg("conv7_tail", case_conv, cin=16, cout=3, k=7, pad=0, bias=True, n=2, h=12, w=12, reflect=3)
+_reg("conv7_tail64", case_conv, cin=64, cout=3, k=7, pad=0, bias=True, n=2, h=16, w=20, reflect=3)  # s2d path
 _reg("conv4_head", case_conv, cin=32, cout=1, k=4, pad=1, bias=True, n=2, h=9, w=9)
 _reg("modconv_p1", case_modconv, cin=16, cout=8, k=3, pad=1, wdim=6, n=3, h=10, w=12)
 _reg("modconv_reflect", case_modconv, cin=8, cout=8, k=3, pad=0, wdim=6, n=2, h=9, w=9, reflect=1)
