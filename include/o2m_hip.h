@@ -158,11 +158,13 @@ int o2m_act_bwd_reduce(const void* g, const void* y, const void* residual,
  *   gfold = fold_reflect(gpad)             (pad == 0: identity)
  *   gx[b,y,x,c]   = gfold[b,y,x,c] * scale[b,c]      (scale NULL: 1)
  *   dots[b,c]    += sum_{y,x} gfold[b,y,x,c] * x[b,y,x,c]   (dots/x NULL: skipped)
- * gpad is [B][H+2p][W+2p][C]; gx, x are [B][H][W][C]; dots fp32 [B][C] zeroed by caller.
+ *   xs[b,y,x,c]   = x[b,y,x,c] * scale[b,c]                  (xs NULL: skipped; needs dots)
+ * gpad is [B][H+2p][W+2p][C]; gx, x, xs are [B][H][W][C]; dots fp32 [B][C] zeroed by caller.
+ * xs is the modulated input, a by-product for o2m_conv2d_wgrad (x is being read anyway).
  */
 int o2m_fold_scale_dot(const void* gpad, const void* x, const float* scale, void* gx,
-                       float* dots, int32_t B, int32_t H, int32_t W, int32_t C, int32_t pad,
-                       int32_t dtype, void* stream);
+                       float* dots, void* xs, int32_t B, int32_t H, int32_t W, int32_t C,
+                       int32_t pad, int32_t dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * InstanceNorm2d (eps, biased variance, no affine; builder.py:164,172,273..; blocks.py:23,27)

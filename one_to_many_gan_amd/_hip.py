@@ -20,7 +20,7 @@ BF16, F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 PAD_ZERO, PAD_REFLECT = 0, 1
 RED_L1, RED_SQ, RED_MOM = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -50,7 +50,7 @@ SIGNATURES = {
     "o2m_style_bwd": (_i32, [_vp] * 14 + [_i32] * 5 + [_f32, _vp]),
     "o2m_act_bwd_reduce": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "o2m_modulate_weights": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
-    "o2m_fold_scale_dot": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "o2m_fold_scale_dot": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "o2m_instnorm_ws_floats": (C.c_size_t, [_i32, _i32, _i32]),
     "o2m_instnorm_stats": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp]),
     "o2m_instnorm_apply": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
@@ -203,10 +203,10 @@ def modulate_weights(w32, s, out):
                                      dtype_code(out.dtype), _stream(out)), "o2m_modulate_weights")
 
 
-def fold_scale_dot(gpad, x, scale, gx, dots, pad):
+def fold_scale_dot(gpad, x, scale, gx, dots, pad, xs=None):
     B, H, W, Cn = gx.shape
-    check(lib().o2m_fold_scale_dot(ptr(gpad), ptr(x), ptr(scale), ptr(gx), ptr(dots), B, H, W, Cn, pad,
-                                   dtype_code(gx.dtype), _stream(gx)), "o2m_fold_scale_dot")
+    check(lib().o2m_fold_scale_dot(ptr(gpad), ptr(x), ptr(scale), ptr(gx), ptr(dots), ptr(xs), B, H, W, Cn,
+                                   pad, dtype_code(gx.dtype), _stream(gx)), "o2m_fold_scale_dot")
 
 
 def instnorm_ws_floats(B, P, Cn):

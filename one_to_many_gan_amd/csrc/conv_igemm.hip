@@ -524,6 +524,10 @@ int launch_dtype(const o2m_conv_desc& d, hipStream_t s) {
     return launch_cfg<T, 128, 128, 2, 2>(d, s);
   }
   if (d.Co > 64) {
+    // short reductions (<= 18 stages) are dominated by per-block prologue / epilogue: 256x64 tiles
+    // need 80 KB of LDS and ~110 VGPRs, so TWO blocks share a CU and overlap each other
+    if (d.KH * d.KW * d.Ci <= 1152 && tiles_for<256, 64>(d) >= 2 * kFillBlocks)
+      return launch_cfg<T, 256, 64, 4, 2>(d, s);
     if (tiles_for<256, 128>(d) >= kFillBlocks) return launch_cfg<T, 256, 128, 4, 2>(d, s);
     return launch_cfg<T, 128, 128, 2, 2>(d, s);
   }

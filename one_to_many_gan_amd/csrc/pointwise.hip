@@ -93,7 +93,7 @@ __global__ __launch_bounds__(NT) void act_bwd_reduce_kernel(const T* g, const T*
 template <typename T>
 __global__ __launch_bounds__(NT) void fold_scale_dot_kernel(const T* gpad, const T* x,
                                                             const float* scale, T* gx,
-                                                            float* dots, int H, int W, int C,
+                                                            float* dots, T* xmod, int H, int W, int C,
                                                             int pad, ChanGeom gm) {
   extern __shared__ float sm[];
   const int b = blockIdx.y, ch = blockIdx.x;
@@ -132,6 +132,11 @@ __global__ __launch_bounds__(NT) void fold_scale_dot_kernel(const T* gpad, const
         load8(x + o, xv);
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[i] += f[i] * xv[i];
+        if (xmod) {  // by-product for the weight gradient: the modulated input x * s
+#pragma unroll
+          for (int i = 0; i < 8; ++i) xv[i] *= sc[i];
+          store8(xmod + o, xv);
+        }
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) f[i] *= sc[i];
@@ -473,7 +478,7 @@ inline unsigned grid_for(long n, int per_block = NT) {
 
 extern "C" {
 
-int o2m_abi_version(void) { return 2; }
+int o2m_abi_version(void) { return 3; }
 
 int o2m_modulate_weights(const float* w32, const float* s, void* out, int32_t B, int32_t Co,
                          int32_t KK, int32_t Ci, int32_t dtype, void* stream) {
@@ -502,17 +507,17 @@ int o2m_act_bwd_reduce(const void* g, const void* y, const void* residual, const
 }
 
 int o2m_fold_scale_dot(const void* gpad, const void* x, const float* scale, void* gx, float* dots,
-                       int32_t B, int32_t H, int32_t W, int32_t C, int32_t pad, int32_t dtype,
+                       void* xs, int32_t B, int32_t H, int32_t W, int32_t C, int32_t pad, int32_t dtype,
                        void* stream) {
   if (!gpad || !gx || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7) || C > 8 * NT || pad < 0)
     return O2M_ERR_BAD_ARG;
-  if (pad >= H || pad >= W || (dots && !x)) return O2M_ERR_BAD_ARG;
+  if (pad >= H || pad >= W || (dots && !x) || (xs && !dots)) return O2M_ERR_BAD_ARG;
   ChanGeom gm = chan_geom(B, H * W, C);
   const size_t lds = (size_t)gm.PL * gm.CV * 8 * sizeof(float);
   hipStream_t s = static_cast<hipStream_t>(stream);
   DISPATCH_T(dtype, hipLaunchKernelGGL(fold_scale_dot_kernel<T>, dim3(gm.nchunks, B), dim3(NT), lds, s,
-                                       (const T*)gpad, (const T*)x, scale, (T*)gx, dots, H, W, C, pad,
-                                       gm));
+                                       (const T*)gpad, (const T*)x, scale, (T*)gx, dots, (T*)xs, H, W, C,
+                                       pad, gm));
   O2M_LAUNCH_CHECK();
   return 0;
 }

@@ -45,8 +45,10 @@ __global__ __launch_bounds__(NT) void style_fwd_kernel(const float* w, const flo
   const int o = blockIdx.y * 64 + ol;
   const int per = (Cip + 3) / 4, i0 = sl * per, i1 = min(Cip, i0 + per);
   float a = 0.f;
-  if (o < Cop)
+  if (o < Cop) {
+#pragma unroll 16
     for (int i = i0; i < i1; ++i) a += Qt[(size_t)i * Cop + o] * s2[i];  // lanes over o: coalesced
+  }
   part[sl * 64 + ol] = a;
   __syncthreads();
   if (sl == 0 && o < Cop)
@@ -78,6 +80,7 @@ __global__ __launch_bounds__(NT) void style_bwd_sample_kernel(
   float t = 0.f;
   if (d && i < Cip) {
     const int per = (Cop + 3) / 4, o0 = sl * per, o1 = min(Cop, o0 + per);
+#pragma unroll 16
     for (int o = o0; o < o1; ++o) t += es[o] * Q[(size_t)o * Cip + i];  // lanes over i: coalesced
   }
   part[sl * 64 + il] = t;
@@ -126,6 +129,7 @@ __global__ __launch_bounds__(NT) void style_bwd_batch_kernel(const float* gs, co
   const int o = blockIdx.x - param_blocks;  // one block per output channel row of gq
   for (int i = threadIdx.x; i < Cip; i += NT) {
     float a = 0.f;
+#pragma unroll 8
     for (int b = 0; b < B; ++b) {
       const float sv = s[(size_t)b * Cip + i];
       a += e[(size_t)b * Cop + o] * sv * sv;

@@ -298,7 +298,7 @@ class _ConvFn(torch.autograd.Function):
             tot = sums[:, 0].sum(0) if sums is not None else gu.float().sum(dim=(0, 1, 2))
             g_bias = tot[: prep.co].to(weight.dtype)
 
-        g_x = dots = None
+        g_x = dots = xs = None
         if need_x or need_s:
             kpad = prep.kh - 1 - (0 if pad_mode == H.PAD_REFLECT else pad)
             hp = Hh + (2 * pad if pad_mode == H.PAD_REFLECT else 0)
@@ -309,8 +309,10 @@ class _ConvFn(torch.autograd.Function):
                 g_x = torch.empty_like(x)
                 if s is not None:
                     dots = torch.zeros((B, cip), dtype=torch.float32, device=dev)
+                    if need_w:  # x * s for the weight gradient, written while x is being read
+                        xs = torch.empty_like(x)
                 H.fold_scale_dot(gxp, x if s is not None else None, s, g_x, dots,
-                                 pad if pad_mode == H.PAD_REFLECT else 0)
+                                 pad if pad_mode == H.PAD_REFLECT else 0, xs=xs)
             else:
                 g_x = gxp
 
@@ -319,7 +321,10 @@ class _ConvFn(torch.autograd.Function):
             # accumulated in the kernel layout across every use of the layer in this backward;
             # converted into weight.grad once, by _finalize_weight_grads
             dw_acc, gq_acc = prep.accumulators(dev)
-            H.conv2d_wgrad(x, gu, dw_acc, in_scale=s, pad=pad, pad_mode=pad_mode)
+            if xs is not None:
+                H.conv2d_wgrad(xs, gu, dw_acc, pad=pad, pad_mode=pad_mode)
+            else:
+                H.conv2d_wgrad(x, gu, dw_acc, in_scale=s, pad=pad, pad_mode=pad_mode)
 
         g_ws = g_tw = g_tb = None
         if s is not None and (need_s or (need_w and d is not None)):
