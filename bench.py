@@ -148,9 +148,18 @@ def kernel_profile(trainer, precision):
     name, (n, secs, flops) = max(agg.items(), key=lambda kv: kv[1][1])
     achieved = flops / secs / 1e12
     peak = MFMA_PEAK[precision] / 1e12
+    # HBM/fabric bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE
+    # with the gfx950 correction), committed under profiles/: PMC cannot be read from inside the run
+    traffic = None
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r01_d_pmc_traffic.json")))
+        if rec.get("kernel") == name:
+            traffic = rec["fabric_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
     return {
         "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-        "frac": round(achieved / peak, 4), "traffic": None,
+        "frac": round(achieved / peak, 4), "traffic": traffic,
         "kernel": name, "launches_per_step": n, "avg_launch_us": round(secs / n * 1e6, 2),
         "share_of_conv_time": round(secs / total_conv_s, 3),
         "all_conv_kernels": {k: {"launches": v[0], "ms": round(v[1] * 1e3, 3),

@@ -74,7 +74,8 @@ PROFILE = None
 
 def _igemm_name(dt, co, scaled):
     t = "bf16" if dt == torch.bfloat16 else "f32x3"
-    tile = "128x128" if co > 64 else ("128x64" if co > 32 else "256x32")
+    # mirrors launch_dtype() in csrc/conv_igemm.hip for the large-M layers that dominate
+    tile = "256x256" if co > 128 else ("256x128" if co > 64 else ("256x64" if co > 32 else "256x32"))
     return f"conv_igemm<{t},{tile},in_scale={int(scaled)}>"
 
 

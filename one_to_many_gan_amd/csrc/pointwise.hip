@@ -212,6 +212,7 @@ __global__ void in_finalize_kernel(const float* partial, float* out, int B, int 
   if (idx >= B * C) return;
   const int b = idx / C, c = idx - b * C;
   float s0 = 0.f, s1 = 0.f;
+#pragma unroll 8
   for (int ch = 0; ch < nchunks; ++ch) {
     const float* p = partial + (((size_t)b * nchunks + ch) * C + c) * 2;
     s0 += p[0];
