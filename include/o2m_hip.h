@@ -124,7 +124,14 @@ typedef struct {
   const float* gy_scale; /* [B][Co] or NULL    */
   int32_t B, H, W, Ci, Co, KH, KW, pad, pad_mode, dtype;
   int32_t splits;        /* >=1: number of slices of the pixel reduction; 0 = auto */
-  int32_t reserved[5];
+  int32_t nseg;          /* 0/1: only (x, gy).  2..8: the reduction also runs over the extra
+                            (x_seg[i], gy_seg[i]) pairs, i = 1..nseg-1, all of the same shape: the
+                            uses of ONE filter in a backward pass (a decoder filter is applied to
+                            5 batches per generator step) reduced by a single launch.  Requires
+                            Wo % 32 == 0 and no in_scale / gy_scale. */
+  int32_t reserved[4];
+  const void* x_seg[8];  /* [0] ignored (= x)  */
+  const void* gy_seg[8]; /* [0] ignored (= gy) */
 } o2m_wgrad_desc;
 int o2m_conv2d_wgrad(const o2m_wgrad_desc* d, void* stream);
 

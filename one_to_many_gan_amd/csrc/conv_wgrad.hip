@@ -113,10 +113,12 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const o2m_wgrad_desc 
   const int H = d.H, W = d.W, Ci = d.Ci, Co = d.Co, KH = d.KH, KW = d.KW, pad = d.pad;
   const int Ho = H + 2 * pad - KH + 1, Wo = W + 2 * pad - KW + 1;
   const int HoWo = Ho * Wo;
-  const int M = d.B * HoWo;
+  const int nseg = d.nseg > 1 ? d.nseg : 1;
+  const int Mseg = d.B * HoWo;  // rows of one (x, gy) segment
+  const int M = nseg * Mseg;
   const int K = KH * KW * Ci;
   const bool reflect = d.pad_mode == O2M_PAD_REFLECT;
-  const bool aligned = (Wo % BMR) == 0;  // a stage never leaves its image row
+  const bool aligned = (Wo % BMR) == 0;  // a stage never leaves its image row (nor its segment)
 
   int bid = xcd_tile_order(blockIdx.x, gridDim.x);  // a split's tiles share x / gy: one XCD
   const int tk = bid % tiles_k; bid /= tiles_k;
@@ -127,8 +129,10 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const o2m_wgrad_desc 
   const int m_end = min(M, m_begin + rows_per_split);
   if (m_begin >= m_end) return;  // uniform per block
 
-  const rsrc_t xr = make_rsrc(d.x, (unsigned)((size_t)d.B * H * W * Ci * ES));
-  const rsrc_t gr = make_rsrc(d.gy, (unsigned)((size_t)M * Co * ES));
+  // buffer descriptors of the segment the current stage reads (rebuilt when it changes)
+  int cur_seg = m_begin / Mseg;  // uniform
+  rsrc_t xr = make_rsrc(cur_seg ? d.x_seg[cur_seg] : d.x, (unsigned)((size_t)d.B * H * W * Ci * ES));
+  rsrc_t gr = make_rsrc(cur_seg ? d.gy_seg[cur_seg] : d.gy, (unsigned)((size_t)Mseg * Co * ES));
 
   const int tid = threadIdx.x;
   // ---- G (upstream gradient) loader: rows grow0 + GRS*j, 8 channels at co0 + gc*8 --------
@@ -147,24 +151,33 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const o2m_wgrad_desc 
   int pb[XLD], py[XLD], px[XLD];
 #pragma unroll
   for (int j = 0; j < XLD; ++j) {
-    const int m = m_begin + xr0 + 16 * j;
+    const int m = (m_begin + xr0 + 16 * j) % Mseg;
     pb[j] = m / HoWo;
     const int rem = m - pb[j] * HoWo;
     py[j] = rem / Wo;
     px[j] = rem - py[j] * Wo;
   }
   // aligned path: (sample, row) of the whole stage are scalar
-  int sb = m_begin / HoWo, sy = (m_begin - sb * HoWo) / Wo, sx = m_begin - sb * HoWo - sy * Wo;
+  const int mb_loc = m_begin % Mseg;
+  int sb = mb_loc / HoWo, sy = (mb_loc - sb * HoWo) / Wo, sx = mb_loc - sb * HoWo - sy * Wo;
 
   Stg<T> sg[GLD], sx_[XLD];
   int xsamp[XLD];  // sample index of each staged X row (only read when XS)
 
   auto load_stage = [&](int ms) {
+    const int seg = ms / Mseg;  // uniform; stages never straddle segments (host: Wo % 32 == 0)
+    if (seg != cur_seg) {
+      cur_seg = seg;
+      xr = make_rsrc(seg ? d.x_seg[seg] : d.x, (unsigned)((size_t)d.B * H * W * Ci * ES));
+      gr = make_rsrc(seg ? d.gy_seg[seg] : d.gy, (unsigned)((size_t)Mseg * Co * ES));
+      sb = 0; sy = 0; sx = 0;  // a new segment starts at its first pixel
+    }
+    const int mloc0 = ms - seg * Mseg;
 #pragma unroll
     for (int j = 0; j < GLD; ++j) {
       const int m = ms + grow0 + GRS * j;
       const bool ok = gcol_ok && (GLD * GRS == BMR || grow0 + GRS * j < BMR) && m < m_end;
-      stg_load(sg[j], gr, ok ? gbase + (unsigned)m * (unsigned)(Co * ES) : OOB_OFF);
+      stg_load(sg[j], gr, ok ? gbase + (unsigned)(mloc0 + grow0 + GRS * j) * (unsigned)(Co * ES) : OOB_OFF);
     }
     if (aligned) {
       int iy = sy + dy;  // per-thread only through dy (constant): cheap
@@ -310,15 +323,19 @@ int launch_cfg(const o2m_wgrad_desc& d, hipStream_t s) {
   constexpr bool F32 = sizeof(T) == 4;
   constexpr int lds = 2 * (F32 ? 2 : 1) * BMR * ((BCO * 2 + 64) + (BKO * 2 + 64));
   const int Ho = d.H + 2 * d.pad - d.KH + 1, Wo = d.W + 2 * d.pad - d.KW + 1;
-  const long M = (long)d.B * Ho * Wo;
+  const long M = (long)(d.nseg > 1 ? d.nseg : 1) * d.B * Ho * Wo;
   const int K = d.KH * d.KW * d.Ci;
   const int tiles_co = (d.Co + BCO - 1) / BCO, tiles_k = (K + BKO - 1) / BKO;
   long splits = d.splits;
   if (splits <= 0) {
-    // every split adds Co*K fp32 atomics: ~900 blocks when that slab is >= 1 MB (measured
-    // optimum on the 256->256, 256->128 and 256->512 layers), ~2048 when it is small
-    const long target = (long)d.Co * K * 4 >= (1 << 20) ? 900 : 2048;
-    splits = (target + (long)tiles_co * tiles_k - 1) / ((long)tiles_co * tiles_k);
+    // measured optima (tools/sweep_wgrad.py, tools/bench_wgrad_seg.py): ~4096 pixels per block,
+    // kept between ~700 and ~2500 blocks in flight (every split adds one Co*K slab of fp32
+    // atomics; too few blocks leave CUs idle)
+    const long tiles = (long)tiles_co * tiles_k;
+    splits = M / 4096;
+    const long lo = (700 + tiles - 1) / tiles, hi = 2500 / tiles;
+    if (splits < lo) splits = lo;
+    if (splits > hi) splits = hi;
     const long max_splits = (M + 8 * BMR - 1) / (8 * BMR);  // >= 8 stages per block
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
@@ -362,6 +379,14 @@ extern "C" int o2m_conv2d_wgrad(const o2m_wgrad_desc* d, void* stream) {
   const long howo = (long)(d->H + 2 * d->pad - d->KH + 1) * (d->W + 2 * d->pad - d->KW + 1);
   if ((long)d->B * d->H * d->W * (long)d->Ci * esz > 0x7fffffffL) return O2M_ERR_UNSUPPORTED;
   if ((long)d->B * howo * (long)d->Co * esz > 0x7fffffffL) return O2M_ERR_UNSUPPORTED;
+  if (d->nseg < 0 || d->nseg > 8) return O2M_ERR_BAD_ARG;
+  if (d->nseg > 1) {
+    const int wo = d->W + 2 * d->pad - d->KW + 1;
+    if (wo % 32 != 0 || d->in_scale || d->gy_scale) return O2M_ERR_BAD_ARG;
+    if ((long)d->nseg * d->B * howo > 0x7fffffffL) return O2M_ERR_UNSUPPORTED;
+    for (int i = 1; i < d->nseg; ++i)
+      if (!d->x_seg[i] || !d->gy_seg[i]) return O2M_ERR_BAD_ARG;
+  }
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (d->dtype == O2M_BF16) return launch_dtype<unsigned short>(*d, s);
   if (d->dtype == O2M_F32) return launch_dtype<float>(*d, s);

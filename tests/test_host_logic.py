@@ -36,7 +36,7 @@ def test_struct_layouts_match_header():
     from one_to_many_gan_amd import _hip
 
     assert ctypes.sizeof(_hip.ConvDesc) == 7 * 8 + 16 * 4
-    assert ctypes.sizeof(_hip.WgradDesc) == 5 * 8 + 16 * 4
+    assert ctypes.sizeof(_hip.WgradDesc) == 5 * 8 + 16 * 4 + 16 * 8
 
 
 def test_hot_path_fails_loudly_without_gpu():
