@@ -76,3 +76,70 @@ def test_wave_specialised_igemm_variant_matches_default():
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append([float(v) for v in r.stdout.split()[-2:]])
     assert abs(outs[0][1] - outs[1][1]) <= 1e-6 * abs(outs[0][1]) and abs(outs[0][0] - outs[1][0]) <= 1e-3 * abs(outs[0][1])
+
+
+@pytest.mark.parametrize("shape", [(16, 64, 64, 256, 256, 3, 1, True), (16, 256, 256, 64, 128, 3, 1, False),
+                                   (16, 255, 255, 64, 128, 4, 1, False)])
+def test_full_size_adjoint_identities(shape):
+    """Size-independent properties at BASELINE config #2 sizes (B = 16), where the CPU oracle is
+    too slow: forward, data-gradient and weight-gradient kernels must be mutually adjoint,
+        <conv(x, w), g> = <x, dgrad(g, w)> = <w, wgrad(x, g)>,
+    and the forward must be linear in x.  fp32 mode (bf16x3), checked in fp64 on the host."""
+    from one_to_many_gan_amd import _hip as H
+
+    B, Hh, Ww, Ci, Co, k, pad, reflect = shape
+    pm = H.PAD_REFLECT if reflect else H.PAD_ZERO
+    torch.manual_seed(3)
+    x = torch.randn(B, Hh, Ww, Ci, device="cuda")
+    w = torch.randn(Co, k, k, Ci, device="cuda") / (Ci * k * k) ** 0.5
+    ho, wo = Hh + 2 * pad - k + 1, Ww + 2 * pad - k + 1
+    g = torch.randn(B, ho, wo, Co, device="cuda")
+    y = torch.empty(B, ho, wo, Co, device="cuda")
+    H.conv2d_fwd(x, w, y, pad=pad, pad_mode=pm, act=H.ACT_NONE)
+    lhs = float((y.double() * g.double()).sum())
+    # weight gradient
+    dw = torch.zeros(Co, k, k, Ci, device="cuda")
+    H.conv2d_wgrad(x, g, dw, pad=pad, pad_mode=pm)
+    via_w = float((dw.double() * w.double()).sum())
+    # data gradient = forward kernel with the flipped / transposed filter (+ fold for reflect)
+    w_d = w.flip(1, 2).permute(3, 1, 2, 0).contiguous()
+    if reflect:
+        gxp = torch.empty(B, Hh + 2 * pad, Ww + 2 * pad, Ci, device="cuda")
+        H.conv2d_fwd(g, w_d, gxp, pad=k - 1, pad_mode=H.PAD_ZERO, act=H.ACT_NONE)
+        gx = torch.empty_like(x)
+        H.fold_scale_dot(gxp, None, None, gx, None, pad)
+    else:
+        gx = torch.empty_like(x)
+        H.conv2d_fwd(g, w_d, gx, pad=k - 1 - pad, pad_mode=H.PAD_ZERO, act=H.ACT_NONE)
+    via_x = float((gx.double() * x.double()).sum())
+    scale = float(y.double().norm() * g.double().norm())
+    assert abs(lhs - via_w) < 2e-5 * scale, (lhs, via_w)
+    assert abs(lhs - via_x) < 2e-5 * scale, (lhs, via_x)
+    # linearity: conv(2x) == 2 conv(x) exactly in the split arithmetic up to rounding
+    y2 = torch.empty_like(y)
+    H.conv2d_fwd((2 * x).contiguous(), w, y2, pad=pad, pad_mode=pm, act=H.ACT_NONE)
+    assert float((y2 - 2 * y).norm() / y2.norm()) < 1e-6
+
+
+def test_c_abi_rejects_bad_arguments():
+    """Error behaviour of the boundary: bad shapes are refused before any launch."""
+    from one_to_many_gan_amd import _hip as H
+
+    x = torch.zeros(1, 8, 8, 8, device="cuda", dtype=torch.bfloat16)
+    w = torch.zeros(8, 3, 3, 8, device="cuda", dtype=torch.bfloat16)
+    y = torch.zeros(1, 8, 8, 8, device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="10001"):  # reflect pad must be < H
+        H.conv2d_fwd(x, w, torch.zeros(1, 22, 22, 8, device="cuda", dtype=torch.bfloat16), pad=8,
+                     pad_mode=H.PAD_REFLECT, act=0)
+    with pytest.raises(RuntimeError, match="10001"):  # channels must be a multiple of 8
+        H.conv2d_fwd(torch.zeros(1, 8, 8, 4, device="cuda", dtype=torch.bfloat16),
+                     torch.zeros(8, 3, 3, 4, device="cuda", dtype=torch.bfloat16), y, pad=1, pad_mode=0, act=0)
+    with pytest.raises(RuntimeError, match="GPU"):
+        H.conv2d_fwd(x.cpu(), w, y, pad=1, pad_mode=0, act=0)
+    with pytest.raises(RuntimeError, match="contiguous"):
+        H.conv2d_fwd(x.permute(0, 2, 1, 3), w, y, pad=1, pad_mode=0, act=0)
+    with pytest.raises(TypeError):
+        H.conv2d_fwd(x.half(), w.half(), y.half(), pad=1, pad_mode=0, act=0)
+    ws = torch.zeros(4, device="cuda")
+    with pytest.raises(RuntimeError, match="10001"):  # tanh has no InstanceNorm backward here
+        H.instnorm_bwd(y, y, torch.zeros(1, 8, 2, device="cuda"), ws, torch.zeros(1, 8, 2, device="cuda"), y, H.ACT_TANH)
