@@ -195,4 +195,4 @@ class StyleExtractor(nn.Module):
 
     def forward(self, x):
         t = _run_trunk(self.model, ops.to_internal(x))
-        return self.model[16](t.float().mean(dim=(1, 2)))
+        return self.model[16](t.mean(dim=(1, 2), dtype=torch.float32))
