@@ -72,10 +72,25 @@ _lib = None
 PROFILE = None
 
 
-def _igemm_name(dt, co, scaled):
+def _igemm_name(dt, co, scaled, m=1 << 30, k=1 << 30):
+    """Mirrors launch_dtype() in csrc/conv_igemm.hip, so the labels map one-to-one onto the
+    template instantiations rocprofv3 reports."""
     t = "bf16" if dt == torch.bfloat16 else "f32x3"
-    # mirrors launch_dtype() in csrc/conv_igemm.hip for the large-M layers that dominate
-    tile = "256x256" if co > 128 else ("256x128" if co > 64 else ("256x64" if co > 32 else "256x32"))
+
+    def tiles(bm, bn):
+        return -(-m // bm) * -(-co // bn)
+
+    if co > 128:
+        tile = "256x256" if tiles(256, 256) >= 256 else "128x128"
+    elif co > 64:
+        if k <= 1152 and tiles(256, 64) >= 512:
+            tile = "256x64"
+        else:
+            tile = "256x128" if tiles(256, 128) >= 256 else "128x128"
+    elif co > 32:
+        tile = "256x64" if tiles(256, 64) >= 256 else "128x64"
+    else:
+        tile = "256x32"
     return f"conv_igemm<{t},{tile},in_scale={int(scaled)}>"
 
 
@@ -154,7 +169,8 @@ def conv2d_fwd(x, w, y, *, in_scale=None, out_scale=None, bias=None, residual=No
     d = ConvDesc(ptr(x), ptr(w), ptr(y), ptr(in_scale), ptr(out_scale), ptr(bias), ptr(residual),
                  B, H, W, Ci, Co, KH, KW, pad, pad_mode, act, dtype_code(x.dtype), wstride, stride)
     flops = 2.0 * y.shape[0] * y.shape[1] * y.shape[2] * Co * KH * KW * Ci
-    _timed(_igemm_name(x.dtype, Co, in_scale is not None), flops, x,
+    _timed(_igemm_name(x.dtype, Co, in_scale is not None, y.shape[0] * y.shape[1] * y.shape[2], KH * KW * Ci),
+           flops, x,
            lambda: check(lib().o2m_conv2d_fwd(C.byref(d), _stream(x)), "o2m_conv2d_fwd"))
 
 
