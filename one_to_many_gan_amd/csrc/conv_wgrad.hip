@@ -328,14 +328,15 @@ int launch_cfg(const o2m_wgrad_desc& d, hipStream_t s) {
   const int tiles_co = (d.Co + BCO - 1) / BCO, tiles_k = (K + BKO - 1) / BKO;
   long splits = d.splits;
   if (splits <= 0) {
-    // measured optima (tools/sweep_wgrad.py, tools/bench_wgrad_seg.py): ~4096 pixels per block,
-    // kept between ~700 and ~2500 blocks in flight (every split adds one Co*K slab of fp32
-    // atomics; too few blocks leave CUs idle)
+    // Whole waves of co-resident blocks (tools/sweep_wgrad.py: 768 = 3 blocks x 256 CUs is the
+    // optimum for the 128-wide tile, 1024 = 1 1/3 waves consistently ~25% slower); more waves only
+    // when one block would reduce more than ~12288 pixels.  Every split adds a Co*K slab of atomics.
     const long tiles = (long)tiles_co * tiles_k;
-    splits = M / 4096;
-    const long lo = (700 + tiles - 1) / tiles, hi = 2500 / tiles;
-    if (splits < lo) splits = lo;
-    if (splits > hi) splits = hi;
+    const long per_cu = lds > 36 * 1024 ? 3 : 4;  // resident blocks per CU (LDS- / VGPR-limited)
+    const long wave = 256 * per_cu;
+    const long rows_one_wave = (M * tiles + wave - 1) / wave;
+    const long waves = (rows_one_wave + 12287) / 12288;
+    splits = wave * waves / tiles;  // round DOWN: two blocks over the wave cost a whole extra round
     const long max_splits = (M + 8 * BMR - 1) / (8 * BMR);  // >= 8 stages per block
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
