@@ -156,6 +156,8 @@ int o2m_wgrad_finalize(float* acc, float* gq, const float* w32, float* grad, int
  * always use the unscaled gu.
  * Replaces the ReLU/LeakyReLU/Tanh backward and the bias reduction of
  * convolution_backward.  `y` is the forward OUTPUT (post-activation).
+ * Reduce-only form (the bias gradient of a conv with no activation, layers.py:84-100): y = NULL
+ * with act = O2M_ACT_NONE and no residual; gu may then be NULL as well (nothing is stored).
  */
 int o2m_act_bwd_reduce(const void* g, const void* y, const void* residual,
                        const float* out_mul, void* gu, float* sums, int32_t B, int32_t P,

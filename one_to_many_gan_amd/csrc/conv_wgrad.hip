@@ -17,6 +17,8 @@
 // shape).  When a 32-pixel stage lies inside one image row (Wo % 32 == 0: every generator
 // layer) the sample / row part of the gather address is scalar.  fp32 mode: bf16x3 split as
 // in conv_igemm.hip.
+#include <cstdlib>
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -28,6 +30,17 @@ constexpr unsigned OOB_OFF = 0x80000000u;
 
 __device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+
+// Segment pointer by constant-index selects: a dynamic index into the by-value descriptor would
+// spill it to scratch and turn the buffer resource into a per-lane value (waterfall loops
+// around every buffer load).
+__device__ __forceinline__ const void* seg_ptr(const void* first, const void* const (&arr)[8], int seg) {
+  const void* p = first;
+#pragma unroll
+  for (int i = 1; i < 8; ++i)
+    if (seg == i) p = arr[i];
+  return p;
 }
 
 template <typename T> struct Stg;
@@ -90,7 +103,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* a) {
   return __builtin_bit_cast(bf16x8, r);
 }
 
-template <typename T, int BCO, int BKO, int WAVES_CO, int WAVES_K, bool XS, bool GS>
+template <typename T, int BCO, int BKO, int WAVES_CO, int WAVES_K, bool XS, bool GS, bool ALIGNED>
 __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const o2m_wgrad_desc d, int tiles_co,
                                                            int tiles_k, int rows_per_split) {
   constexpr bool F32 = sizeof(T) == 4;
@@ -105,8 +118,10 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const o2m_wgrad_desc 
   constexpr int GCH = BCO / 8;                    // 16-B chunks per G row
   constexpr int GLD = (BMR * GCH + NT - 1) / NT;  // G loads per thread per stage
   constexpr int GRS = NT / GCH;                   // G rows covered per pass
-  constexpr int XLD = BMR * (BKO / 8) / NT;       // X loads per thread per stage (= 2)
-  static_assert(WAVES_CO * WAVES_K == 4 && BKO == 128 && NT % GCH == 0, "layout");
+  constexpr int XCH = BKO / 8;                    // 16-B chunks per X row
+  constexpr int XLD = BMR * XCH / NT;             // X loads per thread per stage
+  constexpr int XRS = NT / XCH;                   // X rows covered per pass
+  static_assert(WAVES_CO * WAVES_K == 4 && NT % GCH == 0 && NT % XCH == 0 && XLD * XRS == BMR, "layout");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -118,7 +133,9 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const o2m_wgrad_desc 
   const int M = nseg * Mseg;
   const int K = KH * KW * Ci;
   const bool reflect = d.pad_mode == O2M_PAD_REFLECT;
-  const bool aligned = (Wo % BMR) == 0;  // a stage never leaves its image row (nor its segment)
+  // ALIGNED (Wo % BMR == 0): a stage never leaves its image row (nor its segment).  A template
+  // parameter, not a branch: with both gathers in one kernel their load destinations alias and the
+  // compiler serialises the prefetch with conservative vmcnt waits.
 
   int bid = xcd_tile_order(blockIdx.x, gridDim.x);  // a split's tiles share x / gy: one XCD
   const int tk = bid % tiles_k; bid /= tiles_k;
@@ -131,8 +148,8 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const o2m_wgrad_desc 
 
   // buffer descriptors of the segment the current stage reads (rebuilt when it changes)
   int cur_seg = m_begin / Mseg;  // uniform
-  rsrc_t xr = make_rsrc(cur_seg ? d.x_seg[cur_seg] : d.x, (unsigned)((size_t)d.B * H * W * Ci * ES));
-  rsrc_t gr = make_rsrc(cur_seg ? d.gy_seg[cur_seg] : d.gy, (unsigned)((size_t)Mseg * Co * ES));
+  rsrc_t xr = make_rsrc(seg_ptr(d.x, d.x_seg, cur_seg), (unsigned)((size_t)d.B * H * W * Ci * ES));
+  rsrc_t gr = make_rsrc(seg_ptr(d.gy, d.gy_seg, cur_seg), (unsigned)((size_t)Mseg * Co * ES));
 
   const int tid = threadIdx.x;
   // ---- G (upstream gradient) loader: rows grow0 + GRS*j, 8 channels at co0 + gc*8 --------
@@ -141,7 +158,7 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const o2m_wgrad_desc 
   const unsigned gbase = (unsigned)(co0 + gc * 8) * ES;  // + m*Co*ES per row
 
   // ---- X gather: this thread always fetches the same 8 reduction columns (tap, ci0) -----
-  const int xc = tid & 15, xr0 = tid >> 4;  // rows xr0 and xr0+16
+  const int xc = tid % XCH, xr0 = tid / XCH;  // rows xr0 + XRS*j
   const int kx = k0 + xc * 8;
   const bool kxv = kx < K;
   const int tap = kx / Ci, ci0 = kx - tap * Ci;
@@ -151,7 +168,7 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const o2m_wgrad_desc 
   int pb[XLD], py[XLD], px[XLD];
 #pragma unroll
   for (int j = 0; j < XLD; ++j) {
-    const int m = (m_begin + xr0 + 16 * j) % Mseg;
+    const int m = (m_begin + xr0 + XRS * j) % Mseg;
     pb[j] = m / HoWo;
     const int rem = m - pb[j] * HoWo;
     py[j] = rem / Wo;
@@ -161,15 +178,18 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const o2m_wgrad_desc 
   const int mb_loc = m_begin % Mseg;
   int sb = mb_loc / HoWo, sy = (mb_loc - sb * HoWo) / Wo, sx = mb_loc - sb * HoWo - sy * Wo;
 
-  Stg<T> sg[GLD], sx_[XLD];
-  int xsamp[XLD];  // sample index of each staged X row (only read when XS)
+  // two register sets: stage i+2 is in flight while stage i+1 waits to be written to LDS
+  Stg<T> sg[2][GLD], sx_[2][XLD];
+  int xsamp[2][XLD];  // sample index of each staged X row (only read when XS)
 
-  auto load_stage = [&](int ms) {
-    const int seg = ms / Mseg;  // uniform; stages never straddle segments (host: Wo % 32 == 0)
+  // Always issued, also past m_end (every lane then reads the out-of-range offset = zeros, no
+  // memory traffic): the number of loads in flight stays static, so the waits stay counted.
+  auto load_stage = [&](const int slot, int ms) {
+    const int seg = min(ms / Mseg, nseg - 1);  // uniform; stages never straddle segments
     if (seg != cur_seg) {
       cur_seg = seg;
-      xr = make_rsrc(seg ? d.x_seg[seg] : d.x, (unsigned)((size_t)d.B * H * W * Ci * ES));
-      gr = make_rsrc(seg ? d.gy_seg[seg] : d.gy, (unsigned)((size_t)Mseg * Co * ES));
+      xr = make_rsrc(seg_ptr(d.x, d.x_seg, seg), (unsigned)((size_t)d.B * H * W * Ci * ES));
+      gr = make_rsrc(seg_ptr(d.gy, d.gy_seg, seg), (unsigned)((size_t)Mseg * Co * ES));
       sb = 0; sy = 0; sx = 0;  // a new segment starts at its first pixel
     }
     const int mloc0 = ms - seg * Mseg;
@@ -177,9 +197,9 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const o2m_wgrad_desc 
     for (int j = 0; j < GLD; ++j) {
       const int m = ms + grow0 + GRS * j;
       const bool ok = gcol_ok && (GLD * GRS == BMR || grow0 + GRS * j < BMR) && m < m_end;
-      stg_load(sg[j], gr, ok ? gbase + (unsigned)(mloc0 + grow0 + GRS * j) * (unsigned)(Co * ES) : OOB_OFF);
+      stg_load(sg[slot][j], gr, ok ? gbase + (unsigned)(mloc0 + grow0 + GRS * j) * (unsigned)(Co * ES) : OOB_OFF);
     }
-    if (aligned) {
+    if constexpr (ALIGNED) {
       int iy = sy + dy;  // per-thread only through dy (constant): cheap
       bool rowok = kxv;
       if (reflect) iy = iy < 0 ? -iy : (iy >= H ? 2 * H - 2 - iy : iy);
@@ -187,12 +207,12 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const o2m_wgrad_desc 
       const int rowbase = (sb * H + iy) * W;
 #pragma unroll
       for (int j = 0; j < XLD; ++j) {
-        int ix = sx + xr0 + 16 * j + dx;
-        bool ok = rowok && ms + xr0 + 16 * j < m_end;
+        int ix = sx + xr0 + XRS * j + dx;
+        bool ok = rowok && ms + xr0 + XRS * j < m_end;
         if (reflect) ix = ix < 0 ? -ix : (ix >= W ? 2 * W - 2 - ix : ix);
         else ok = ok && (unsigned)ix < (unsigned)W;
-        stg_load(sx_[j], xr, ok ? (unsigned)((rowbase + ix) * Ci + ci0) * ES : OOB_OFF);
-        xsamp[j] = sb;
+        stg_load(sx_[slot][j], xr, ok ? (unsigned)((rowbase + ix) * Ci + ci0) * ES : OOB_OFF);
+        xsamp[slot][j] = sb;
       }
       sx += BMR;
       if (sx >= Wo) { sx = 0; if (++sy >= Ho) { sy = 0; ++sb; } }
@@ -200,15 +220,15 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const o2m_wgrad_desc 
 #pragma unroll
       for (int j = 0; j < XLD; ++j) {
         int iy = py[j] + dy, ix = px[j] + dx;
-        bool ok = kxv && ms + xr0 + 16 * j < m_end;
+        bool ok = kxv && ms + xr0 + XRS * j < m_end;
         if (reflect) {
           iy = iy < 0 ? -iy : (iy >= H ? 2 * H - 2 - iy : iy);
           ix = ix < 0 ? -ix : (ix >= W ? 2 * W - 2 - ix : ix);
         } else {
           ok = ok && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
         }
-        stg_load(sx_[j], xr, ok ? (unsigned)(((pb[j] * H + iy) * W + ix) * Ci + ci0) * ES : OOB_OFF);
-        xsamp[j] = pb[j];
+        stg_load(sx_[slot][j], xr, ok ? (unsigned)(((pb[j] * H + iy) * W + ix) * Ci + ci0) * ES : OOB_OFF);
+        xsamp[slot][j] = pb[j];
         px[j] += BMR;
         while (px[j] >= Wo) { px[j] -= Wo; ++py[j]; }
         while (py[j] >= Ho) { py[j] -= Ho; ++pb[j]; }
@@ -216,7 +236,7 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const o2m_wgrad_desc 
     }
   };
 
-  auto store_stage = [&](int stage, int ms) {
+  auto store_stage = [&](const int slot, int stage, int ms) {
     char* base = smem + stage * STAGE_BYTES;
     char* g_hi = base;
     char* g_lo = base + G_BYTES;
@@ -230,13 +250,13 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const o2m_wgrad_desc 
         const int m = min(ms + grow0 + GRS * j, M - 1);
         sc = d.gy_scale + (size_t)(m / HoWo) * Co + min(co0 + gc * 8, Co - 8);
       }
-      put8<T, GS>(sg[j], sc, g_hi, g_lo, (grow0 + GRS * j) * GSTR + gc * 16);
+      put8<T, GS>(sg[slot][j], sc, g_hi, g_lo, (grow0 + GRS * j) * GSTR + gc * 16);
     }
 #pragma unroll
     for (int j = 0; j < XLD; ++j) {
       const float* sc = nullptr;
-      if constexpr (XS) sc = d.in_scale + (size_t)min(xsamp[j], d.B - 1) * Ci + (kxv ? ci0 : 0);
-      put8<T, XS>(sx_[j], sc, x_hi, x_lo, (xr0 + 16 * j) * XSTR + xc * 16);
+      if constexpr (XS) sc = d.in_scale + (size_t)min(xsamp[slot][j], d.B - 1) * Ci + (kxv ? ci0 : 0);
+      put8<T, XS>(sx_[slot][j], sc, x_hi, x_lo, (xr0 + XRS * j) * XSTR + xc * 16);
     }
   };
 
@@ -288,17 +308,22 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const o2m_wgrad_desc 
   };
 
   // ---- main loop ------------------------------------------------------------------------------
-  load_stage(m_begin);
-  store_stage(0, m_begin);
+  // prefetch distance 2: global loads of stage i+2 are issued before the MFMAs of stage i, the
+  // registers of stage i+1 (issued one iteration earlier) go to LDS after them
+  load_stage(0, m_begin);
+  load_stage(1, m_begin + BMR);
+  store_stage(0, 0, m_begin);
   __syncthreads();
-  int cur = 0;
-  for (int ms = m_begin; ms < m_end; ms += BMR) {
-    const bool more = ms + BMR < m_end;
-    if (more) load_stage(ms + BMR);
-    compute(cur);
-    if (more) store_stage(cur ^ 1, ms + BMR);
+  for (int ms = m_begin; ms < m_end; ms += 2 * BMR) {
+    load_stage(0, ms + 2 * BMR);
+    compute(0);
+    store_stage(1, 1, ms + BMR);
     __syncthreads();
-    cur ^= 1;
+    if (ms + BMR >= m_end) break;
+    load_stage(1, ms + 3 * BMR);
+    compute(1);
+    store_stage(0, 0, ms + 2 * BMR);
+    __syncthreads();
   }
 
   // ---- epilogue: lane owns one k column; fp32 atomics, 128-B segments per half-wave ----
@@ -317,9 +342,8 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const o2m_wgrad_desc 
   }
 }
 
-template <typename T, int BCO, int WAVES_CO, int WAVES_K>
+template <typename T, int BCO, int BKO, int WAVES_CO, int WAVES_K>
 int launch_cfg(const o2m_wgrad_desc& d, hipStream_t s) {
-  constexpr int BKO = 128;
   constexpr bool F32 = sizeof(T) == 4;
   constexpr int lds = 2 * (F32 ? 2 : 1) * BMR * ((BCO * 2 + 64) + (BKO * 2 + 64));
   const int Ho = d.H + 2 * d.pad - d.KH + 1, Wo = d.W + 2 * d.pad - d.KW + 1;
@@ -332,7 +356,8 @@ int launch_cfg(const o2m_wgrad_desc& d, hipStream_t s) {
     // optimum for the 128-wide tile, 1024 = 1 1/3 waves consistently ~25% slower); more waves only
     // when one block would reduce more than ~12288 pixels.  Every split adds a Co*K slab of atomics.
     const long tiles = (long)tiles_co * tiles_k;
-    const long per_cu = lds > 36 * 1024 ? 3 : 4;  // resident blocks per CU (LDS- / VGPR-limited)
+    // resident blocks per CU: 128 accumulator registers -> 2; else LDS- (3) or VGPR-limited (4)
+    const long per_cu = BCO * BKO >= 256 * 128 ? 2 : (lds > 36 * 1024 ? 3 : 4);
     const long wave = 256 * per_cu;
     const long rows_one_wave = (M * tiles + wave - 1) / wave;
     const long waves = (rows_one_wave + 12287) / 12288;
@@ -352,19 +377,36 @@ int launch_cfg(const o2m_wgrad_desc& d, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NT), lds, s, d, tiles_co, tiles_k, (int)rows);
   };
   const bool xs = d.in_scale != nullptr, gs = d.gy_scale != nullptr;
-  if (xs && gs) go(conv_wgrad_kernel<T, BCO, BKO, WAVES_CO, WAVES_K, true, true>);
-  else if (xs) go(conv_wgrad_kernel<T, BCO, BKO, WAVES_CO, WAVES_K, true, false>);
-  else if (gs) go(conv_wgrad_kernel<T, BCO, BKO, WAVES_CO, WAVES_K, false, true>);
-  else go(conv_wgrad_kernel<T, BCO, BKO, WAVES_CO, WAVES_K, false, false>);
+  auto pick = [&](auto al) {
+    constexpr bool AL = decltype(al)::value;
+    if (xs && gs) go(conv_wgrad_kernel<T, BCO, BKO, WAVES_CO, WAVES_K, true, true, AL>);
+    else if (xs) go(conv_wgrad_kernel<T, BCO, BKO, WAVES_CO, WAVES_K, true, false, AL>);
+    else if (gs) go(conv_wgrad_kernel<T, BCO, BKO, WAVES_CO, WAVES_K, false, true, AL>);
+    else go(conv_wgrad_kernel<T, BCO, BKO, WAVES_CO, WAVES_K, false, false, AL>);
+  };
+  if (Wo % BMR == 0) pick(std::true_type{});
+  else pick(std::false_type{});
   O2M_LAUNCH_CHECK();
   return 0;
 }
 
 template <typename T>
 int launch_dtype(const o2m_wgrad_desc& d, hipStream_t s) {
-  if (d.Co > 64) return launch_cfg<T, 128, 2, 2>(d, s);
-  if (d.Co > 32) return launch_cfg<T, 64, 2, 2>(d, s);
-  return launch_cfg<T, 32, 1, 4>(d, s);
+  // O2M_WGRAD_TILES=small keeps the 128-wide tiles (A/B measurements)
+  static const bool small = [] { const char* e = getenv("O2M_WGRAD_TILES"); return e && e[0] == 's'; }();
+  const int K = d.KH * d.KW * d.Ci;
+  if (!small) {
+    // 128x64 / 64x128 wave tiles (1.5x fewer LDS fragment bytes per MFMA) where they measured
+    // faster (tools/sweep_wgrad.py): long reductions for wide layers, K a multiple of 256
+    const long M = (long)(d.nseg > 1 ? d.nseg : 1) * d.B * (d.H + 2 * d.pad - d.KH + 1) *
+                   (d.W + 2 * d.pad - d.KW + 1);
+    if (d.Co > 256 || (d.Co > 128 && M >= 100000)) return launch_cfg<T, 256, 128, 2, 2>(d, s);
+    if (d.Co > 64 && d.Co <= 128 && K % 256 == 0 && sizeof(T) == 2)  // fp32 split: would spill
+      return launch_cfg<T, 128, 256, 2, 2>(d, s);
+  }
+  if (d.Co > 64) return launch_cfg<T, 128, 128, 2, 2>(d, s);
+  if (d.Co > 32) return launch_cfg<T, 64, 128, 2, 2>(d, s);
+  return launch_cfg<T, 32, 128, 1, 4>(d, s);
 }
 
 }  // namespace

@@ -65,17 +65,18 @@ __global__ __launch_bounds__(NT) void act_bwd_reduce_kernel(const T* g, const T*
       const size_t o = ((size_t)b * P + p) * C + cv * 8;
       float gv[8], yv[8], rv[8], ov[8];
       load8(g + o, gv);
-      load8(y + o, yv);
+      if (y) load8(y + o, yv);
       if (res) load8(res + o, rv);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        float u = res ? yv[i] - rv[i] : yv[i];
-        float d = gv[i] * act_bwd_from_out(u, act);
+        // y == nullptr: reduce-only call (identity activation), sums[.][1] stays 0
+        float u = y ? (res ? yv[i] - rv[i] : yv[i]) : 0.f;
+        float d = y ? gv[i] * act_bwd_from_out(u, act) : gv[i];
         ov[i] = d * mul[i];
         acc[i] += d;
         acc[8 + i] += d * u;
       }
-      store8(gu + o, ov);
+      if (gu) store8(gu + o, ov);
     }
   }
   lanes_reduce<16>(acc, cv, pl, gm.CV, gm.PL, sm);
@@ -495,8 +496,10 @@ int o2m_modulate_weights(const float* w32, const float* s, void* out, int32_t B,
 int o2m_act_bwd_reduce(const void* g, const void* y, const void* residual, const float* out_mul,
                        void* gu, float* sums, int32_t B, int32_t P, int32_t C, int32_t act,
                        int32_t dtype, void* stream) {
-  if (!g || !y || !gu || !sums || B <= 0 || P <= 0 || C <= 0 || (C & 7) || C > 8 * NT)
-    return O2M_ERR_BAD_ARG;
+  if (!g || !sums || B <= 0 || P <= 0 || C <= 0 || (C & 7) || C > 8 * NT) return O2M_ERR_BAD_ARG;
+  // y may be omitted only for the identity activation without residual (reduce-only: gu optional)
+  if (!y && (act != O2M_ACT_NONE || residual)) return O2M_ERR_BAD_ARG;
+  if (y && !gu) return O2M_ERR_BAD_ARG;
   ChanGeom gm = chan_geom(B, P, C);
   const size_t lds = (size_t)gm.PL * gm.CV * 16 * sizeof(float);
   hipStream_t s = static_cast<hipStream_t>(stream);

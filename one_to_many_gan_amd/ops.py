@@ -320,7 +320,10 @@ class _ConvFn(torch.autograd.Function):
 
         g_bias = None
         if ctx.has_bias and need_b:
-            tot = sums[:, 0].sum(0) if sums is not None else gu.float().sum(dim=(0, 1, 2))
+            if sums is None:  # no activation: reduce-only pass over g (one read, nothing stored)
+                sums = torch.zeros((B, 2, prep.cop), dtype=torch.float32, device=dev)
+                H.act_bwd_reduce(g, None, None, None, None, sums, H.ACT_NONE)
+            tot = sums[:, 0].sum(0)
             g_bias = tot[: prep.co].to(weight.dtype)
 
         g_x = dots = xs = None
