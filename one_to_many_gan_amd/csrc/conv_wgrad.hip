@@ -314,17 +314,21 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const o2m_wgrad_desc 
   load_stage(1, m_begin + BMR);
   store_stage(0, 0, m_begin);
   __syncthreads();
-  for (int ms = m_begin; ms < m_end; ms += 2 * BMR) {
+  // No break inside the loop: an exit edge from the middle would reach the loop header with the
+  // first half's loads pending and make the compiler wait for them there.
+  const int nst = (m_end - m_begin + BMR - 1) / BMR;
+  int ms = m_begin;
+  for (int pr = nst >> 1; pr > 0; --pr, ms += 2 * BMR) {
     load_stage(0, ms + 2 * BMR);
     compute(0);
     store_stage(1, 1, ms + BMR);
     __syncthreads();
-    if (ms + BMR >= m_end) break;
     load_stage(1, ms + 3 * BMR);
     compute(1);
     store_stage(0, 0, ms + 2 * BMR);
     __syncthreads();
   }
+  if (nst & 1) compute(0);  // odd stage count: the last stage sits in buffer 0
 
   // ---- epilogue: lane owns one k column; fp32 atomics, 128-B segments per half-wave ----
   const int lr = lane & 31, lh = lane >> 5;
