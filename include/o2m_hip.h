@@ -129,7 +129,9 @@ typedef struct {
                             uses of ONE filter in a backward pass (a decoder filter is applied to
                             5 batches per generator step) reduced by a single launch.  Requires
                             Wo % 32 == 0 and no in_scale / gy_scale. */
-  int32_t reserved[4];
+  int32_t stride;        /* 0/1: unit stride; >1: gy is the output of a strided conv
+                            (Ho = (H + 2 pad - KH) / stride + 1)                          */
+  int32_t reserved[3];
   const void* x_seg[8];  /* [0] ignored (= x)  */
   const void* gy_seg[8]; /* [0] ignored (= gy) */
 } o2m_wgrad_desc;

@@ -20,7 +20,7 @@ BF16, F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 PAD_ZERO, PAD_REFLECT = 0, 1
 RED_L1, RED_SQ, RED_MOM = 0, 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -37,7 +37,7 @@ class WgradDesc(C.Structure):
     _fields_ = [("x", _vp), ("gy", _vp), ("dw", _vp), ("in_scale", _vp), ("gy_scale", _vp),
                 ("B", _i32), ("H", _i32), ("W", _i32), ("Ci", _i32), ("Co", _i32), ("KH", _i32),
                 ("KW", _i32), ("pad", _i32), ("pad_mode", _i32), ("dtype", _i32), ("splits", _i32),
-                ("nseg", _i32), ("reserved", _i32 * 4), ("x_seg", _vp * 8), ("gy_seg", _vp * 8)]
+                ("nseg", _i32), ("stride", _i32), ("reserved", _i32 * 3), ("x_seg", _vp * 8), ("gy_seg", _vp * 8)]
 
 
 # name -> (restype, argtypes); mirrors include/o2m_hip.h one for one
@@ -174,12 +174,12 @@ def conv2d_fwd(x, w, y, *, in_scale=None, out_scale=None, bias=None, residual=No
            lambda: check(lib().o2m_conv2d_fwd(C.byref(d), _stream(x)), "o2m_conv2d_fwd"))
 
 
-def conv2d_wgrad(x, gy, dw, *, in_scale=None, gy_scale=None, pad, pad_mode, splits=0, more=()):
+def conv2d_wgrad(x, gy, dw, *, in_scale=None, gy_scale=None, pad, pad_mode, splits=0, more=(), stride=1):
     """``more``: extra (x, gy) pairs of the same shape reduced by the same launch (<= 7)."""
     B, H, W, Ci = x.shape
     Co, KH, KW, _ = dw.shape
     d = WgradDesc(ptr(x), ptr(gy), ptr(dw), ptr(in_scale), ptr(gy_scale), B, H, W, Ci, Co, KH, KW,
-                  pad, pad_mode, dtype_code(x.dtype), splits, 1 + len(more))
+                  pad, pad_mode, dtype_code(x.dtype), splits, 1 + len(more), stride)
     for i, (xi, gi) in enumerate(more, start=1):
         if xi.shape != x.shape or gi.shape != gy.shape or xi.dtype != x.dtype:
             raise RuntimeError("wgrad segments must share one shape")

@@ -126,7 +126,8 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const o2m_wgrad_desc 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int H = d.H, W = d.W, Ci = d.Ci, Co = d.Co, KH = d.KH, KW = d.KW, pad = d.pad;
-  const int Ho = H + 2 * pad - KH + 1, Wo = W + 2 * pad - KW + 1;
+  const int st = d.stride > 0 ? d.stride : 1;
+  const int Ho = (H + 2 * pad - KH) / st + 1, Wo = (W + 2 * pad - KW) / st + 1;
   const int HoWo = Ho * Wo;
   const int nseg = d.nseg > 1 ? d.nseg : 1;
   const int Mseg = d.B * HoWo;  // rows of one (x, gy) segment
@@ -200,14 +201,14 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const o2m_wgrad_desc 
       stg_load(sg[slot][j], gr, ok ? gbase + (unsigned)(mloc0 + grow0 + GRS * j) * (unsigned)(Co * ES) : OOB_OFF);
     }
     if constexpr (ALIGNED) {
-      int iy = sy + dy;  // per-thread only through dy (constant): cheap
+      int iy = sy * st + dy;  // per-thread only through dy (constant): cheap
       bool rowok = kxv;
       if (reflect) iy = iy < 0 ? -iy : (iy >= H ? 2 * H - 2 - iy : iy);
       else rowok = rowok && (unsigned)iy < (unsigned)H;
       const int rowbase = (sb * H + iy) * W;
 #pragma unroll
       for (int j = 0; j < XLD; ++j) {
-        int ix = sx + xr0 + XRS * j + dx;
+        int ix = (sx + xr0 + XRS * j) * st + dx;
         bool ok = rowok && ms + xr0 + XRS * j < m_end;
         if (reflect) ix = ix < 0 ? -ix : (ix >= W ? 2 * W - 2 - ix : ix);
         else ok = ok && (unsigned)ix < (unsigned)W;
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const o2m_wgrad_desc 
     } else {
 #pragma unroll
       for (int j = 0; j < XLD; ++j) {
-        int iy = py[j] + dy, ix = px[j] + dx;
+        int iy = py[j] * st + dy, ix = px[j] * st + dx;
         bool ok = kxv && ms + xr0 + XRS * j < m_end;
         if (reflect) {
           iy = iy < 0 ? -iy : (iy >= H ? 2 * H - 2 - iy : iy);
@@ -350,7 +351,8 @@ template <typename T, int BCO, int BKO, int WAVES_CO, int WAVES_K>
 int launch_cfg(const o2m_wgrad_desc& d, hipStream_t s) {
   constexpr bool F32 = sizeof(T) == 4;
   constexpr int lds = 2 * (F32 ? 2 : 1) * BMR * ((BCO * 2 + 64) + (BKO * 2 + 64));
-  const int Ho = d.H + 2 * d.pad - d.KH + 1, Wo = d.W + 2 * d.pad - d.KW + 1;
+  const int st = d.stride > 0 ? d.stride : 1;
+  const int Ho = (d.H + 2 * d.pad - d.KH) / st + 1, Wo = (d.W + 2 * d.pad - d.KW) / st + 1;
   const long M = (long)(d.nseg > 1 ? d.nseg : 1) * d.B * Ho * Wo;
   const int K = d.KH * d.KW * d.Ci;
   const int tiles_co = (d.Co + BCO - 1) / BCO, tiles_k = (K + BKO - 1) / BKO;
@@ -402,8 +404,9 @@ int launch_dtype(const o2m_wgrad_desc& d, hipStream_t s) {
   if (!small) {
     // 128x64 / 64x128 wave tiles (1.5x fewer LDS fragment bytes per MFMA) where they measured
     // faster (tools/sweep_wgrad.py): long reductions for wide layers, K a multiple of 256
-    const long M = (long)(d.nseg > 1 ? d.nseg : 1) * d.B * (d.H + 2 * d.pad - d.KH + 1) *
-                   (d.W + 2 * d.pad - d.KW + 1);
+    const int st = d.stride > 0 ? d.stride : 1;
+    const long M = (long)(d.nseg > 1 ? d.nseg : 1) * d.B * ((d.H + 2 * d.pad - d.KH) / st + 1) *
+                   ((d.W + 2 * d.pad - d.KW) / st + 1);
     if (d.Co > 256 || (d.Co > 128 && M >= 100000)) return launch_cfg<T, 256, 128, 2, 2>(d, s);
     if (d.Co > 64 && d.Co <= 128 && K % 256 == 0 && sizeof(T) == 2)  // fp32 split: would spill
       return launch_cfg<T, 128, 256, 2, 2>(d, s);
@@ -423,12 +426,14 @@ extern "C" int o2m_conv2d_wgrad(const o2m_wgrad_desc* d, void* stream) {
   if (d->pad_mode == O2M_PAD_REFLECT && (d->pad >= d->H || d->pad >= d->W)) return O2M_ERR_BAD_ARG;
   if (d->pad_mode != O2M_PAD_ZERO && d->pad_mode != O2M_PAD_REFLECT) return O2M_ERR_BAD_ARG;
   const long esz = d->dtype == O2M_F32 ? 4 : 2;
-  const long howo = (long)(d->H + 2 * d->pad - d->KH + 1) * (d->W + 2 * d->pad - d->KW + 1);
+  if (d->stride < 0 || d->stride > 8) return O2M_ERR_BAD_ARG;
+  const int st = d->stride > 0 ? d->stride : 1;
+  const long howo = (long)((d->H + 2 * d->pad - d->KH) / st + 1) * ((d->W + 2 * d->pad - d->KW) / st + 1);
   if ((long)d->B * d->H * d->W * (long)d->Ci * esz > 0x7fffffffL) return O2M_ERR_UNSUPPORTED;
   if ((long)d->B * howo * (long)d->Co * esz > 0x7fffffffL) return O2M_ERR_UNSUPPORTED;
   if (d->nseg < 0 || d->nseg > 8) return O2M_ERR_BAD_ARG;
   if (d->nseg > 1) {
-    const int wo = d->W + 2 * d->pad - d->KW + 1;
+    const int wo = (d->W + 2 * d->pad - d->KW) / st + 1;
     if (wo % 32 != 0 || d->in_scale || d->gy_scale) return O2M_ERR_BAD_ARG;
     if ((long)d->nseg * d->B * howo > 0x7fffffffL) return O2M_ERR_UNSUPPORTED;
     for (int i = 1; i < d->nseg; ++i)
