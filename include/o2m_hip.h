@@ -83,6 +83,17 @@ typedef struct {
 } o2m_conv_desc;
 int o2m_conv2d_fwd(const o2m_conv_desc* d, void* stream);
 
+/* Kernel-side forms of one equalised-LR filter (layers.py:12-24: W*c is recomputed on every
+ * forward).  w is the parameter, fp32 [Co][Ci][KK] (KK = KH*KW).  Written:
+ *   full fp32 [Cop][KK][Cip] = W*c, zero beyond (Co, Ci);   w_f = full in `dtype`;
+ *   w_d (`dtype`) [Cip][KK][Cop] = the data-gradient filter (taps reversed, in/out swapped);
+ *   q fp32 [Cop][Cip] = sum_kk full^2 and qt = its transpose (layers.py:156-161 factored; both
+ *   NULL for an unmodulated conv).
+ */
+int o2m_prepare_weights(const float* w, float* full, void* w_f, void* w_d, float* q, float* qt,
+                        int32_t Co, int32_t Ci, int32_t KK, int32_t Cop, int32_t Cip, float c,
+                        int32_t dtype, void* stream);
+
 /* Per-sample pre-modulated filters for the forward modulated conv:
  *   out[b][o][kh][kw][i] = (dtype) ( w32[o][kh][kw][i] * s[b][i] )
  * i.e. layers.py:152-154 (weights * s) without the demodulation, which stays an epilogue
@@ -204,10 +215,16 @@ int o2m_instnorm_bwd(const void* g, const void* x, const float* mean_rstd, float
  * host composes the 1-D operators (one_to_many_gan_amd/resample.py) and passes the taps.
  * sy/sx: int32 [Ho]/[Wo] first source index; wy/wx: fp32 [Ho][T]/[Wo][T], zero padded.
  * Taps must stay in range: 0 <= s[o] and s[o]+T <= source size (host guarantees).
+ * Ty / Tx: taps per axis (wy is [Ho][Ty], wx is [Wo][Tx]).  span_y / span_x: if that axis' starts
+ * are non-decreasing, its largest step s[o+1]-s[o] (>= 1: selects the kernel that shares one
+ * (Ty+span_y) x (Tx+span_x) input patch between 2x2 outputs); 0 = no promise, one output per
+ * thread (needs Ty == Tx).  A 6-tap operator (the transposed upsample) is run by the host as a
+ * vertical and a horizontal pass with identity taps on the other axis.
  */
 int o2m_resample2d(const void* x, void* y, const int32_t* sy, const float* wy,
                    const int32_t* sx, const float* wx, int32_t B, int32_t H, int32_t W,
-                   int32_t Ho, int32_t Wo, int32_t C, int32_t T, int32_t dtype, void* stream);
+                   int32_t Ho, int32_t Wo, int32_t C, int32_t Ty, int32_t Tx, int32_t span_y,
+                   int32_t span_x, int32_t dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Layout conversion at the public (logical NCHW fp32) boundary.

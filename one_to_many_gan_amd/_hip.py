@@ -20,7 +20,7 @@ BF16, F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 PAD_ZERO, PAD_REFLECT = 0, 1
 RED_L1, RED_SQ, RED_MOM = 0, 1, 2
-ABI_VERSION = 5
+ABI_VERSION = 8
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -49,6 +49,8 @@ SIGNATURES = {
     "o2m_style_fwd": (_i32, [_vp] * 6 + [_i32] * 5 + [_f32, _f32, _vp]),
     "o2m_style_bwd": (_i32, [_vp] * 14 + [_i32] * 5 + [_f32, _vp]),
     "o2m_act_bwd_reduce": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "o2m_prepare_weights": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, C.c_float,
+                                   _i32, _vp]),
     "o2m_modulate_weights": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "o2m_fold_scale_dot": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "o2m_instnorm_ws_floats": (C.c_size_t, [_i32, _i32, _i32]),
@@ -56,7 +58,7 @@ SIGNATURES = {
     "o2m_instnorm_apply": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "o2m_instnorm_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "o2m_resample2d": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
-                              _i32, _vp]),
+                              _i32, _i32, _i32, _i32, _vp]),
     "o2m_pack_nchw": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "o2m_unpack_nhwc": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "o2m_reduce_blocks": (_i32, [_i64]),
@@ -219,6 +221,14 @@ def wgrad_finalize(acc, gq, w32, grad, co, ci, c):
                                    _stream(acc)), "o2m_wgrad_finalize")
 
 
+def prepare_weights(w, full, w_f, w_d, q, qt, c):
+    """W*c in the kernel layouts (see o2m_prepare_weights); ``w`` is the raw (Co,Ci,KH,KW) parameter."""
+    Co, Ci, KH, KW = w.shape
+    Cop, _, _, Cip = full.shape
+    check(lib().o2m_prepare_weights(ptr(w), ptr(full), ptr(w_f), ptr(w_d), ptr(q), ptr(qt), Co, Ci, KH * KW,
+                                    Cop, Cip, c, dtype_code(w_f.dtype), _stream(w)), "o2m_prepare_weights")
+
+
 def modulate_weights(w32, s, out):
     """out[b,o,kh,kw,i] = w32[o,kh,kw,i] * s[b,i] in the dtype of ``out``."""
     Co, KH, KW, Ci = w32.shape
@@ -254,11 +264,13 @@ def instnorm_bwd(g, x, mean_rstd, partial, gsums, gx, act):
                                  Cn, act, dtype_code(x.dtype), _stream(x)), "o2m_instnorm_bwd")
 
 
-def resample2d(x, y, sy, wy, sx, wx, T):
+def resample2d(x, y, sy, wy, sx, wx, ty, tx=None, span_y=0, span_x=0):
+    """``ty`` / ``tx``: taps per axis (wy is [Ho][ty], wx is [Wo][tx]); spans: see resample.Taps."""
     B, H, W, Cn = x.shape
     _, Ho, Wo, _ = y.shape
+    tx = ty if tx is None else tx
     check(lib().o2m_resample2d(ptr(x), ptr(y), ptr(sy), ptr(wy), ptr(sx), ptr(wx), B, H, W, Ho, Wo, Cn,
-                               T, dtype_code(x.dtype), _stream(x)), "o2m_resample2d")
+                               ty, tx, span_y, span_x, dtype_code(x.dtype), _stream(x)), "o2m_resample2d")
 
 
 def pack_nchw(src, dst):

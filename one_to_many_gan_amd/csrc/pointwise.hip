@@ -232,40 +232,61 @@ __global__ void in_finalize_kernel(const float* partial, float* out, int B, int 
 }
 
 // MODE 0: y = act((x-mean)*rstd) + res ;  MODE 1: gx = rstd*(gh - m1 - xh*m2)
+// Same block geometry as the reductions (one pixel chunk of one sample per block, a thread keeps
+// its 8 channels): the per-(b,c) statistics sit in registers and the pixel walk needs no integer
+// division; four pixels are in flight per thread.
 template <typename T, int MODE>
-__global__ __launch_bounds__(NT) void in_apply_kernel(const T* x, const T* g,
-                                                      const float* mean_rstd, const float* gsums,
-                                                      const T* res, T* out, int P, int C, int act,
-                                                      long nvec) {
-  const int CV = C / 8;
-  for (long v = (long)blockIdx.x * NT + threadIdx.x; v < nvec; v += (long)gridDim.x * NT) {
-    const int cv = (int)(v % CV);
-    const long bp = v / CV;
-    const int b = (int)(bp / P);
-    const size_t o = (size_t)v * 8;
+__global__ __launch_bounds__(NT) void in_apply_kernel(const T* __restrict__ x, const T* __restrict__ g,
+                                                      const float* __restrict__ mean_rstd,
+                                                      const float* __restrict__ gsums,
+                                                      const T* __restrict__ res, T* __restrict__ out,
+                                                      int P, int C, int act, ChanGeom gm) {
+  const int b = blockIdx.y, ch = blockIdx.x;
+  const int cv = threadIdx.x % gm.CV, pl = threadIdx.x / gm.CV;
+  if (pl >= gm.PL) return;
+  const int pe = min(P, (ch + 1) * gm.chunk);
+  float mean[8], rstd[8], m1[8], m2[8];
+  {
     const float* mr = mean_rstd + ((size_t)b * C + cv * 8) * 2;
-    float xv[8], ov[8];
-    load8(x + o, xv);
-    if (MODE == 0) {
-      float rv[8];
-      if (res) load8(res + o, rv);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        float t = act_fwd((xv[i] - mr[2 * i]) * mr[2 * i + 1], act);
-        ov[i] = res ? t + rv[i] : t;
-      }
-    } else {
-      float gv[8];
-      load8(g + o, gv);
+    for (int i = 0; i < 8; ++i) { mean[i] = mr[2 * i]; rstd[i] = mr[2 * i + 1]; m1[i] = m2[i] = 0.f; }
+    if (MODE == 1) {
       const float* gs = gsums + ((size_t)b * C + cv * 8) * 2;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        float xh = (xv[i] - mr[2 * i]) * mr[2 * i + 1];
-        float gh = gv[i] * act_bwd_from_out(xh, act);
-        ov[i] = mr[2 * i + 1] * (gh - gs[2 * i] - xh * gs[2 * i + 1]);
+      for (int i = 0; i < 8; ++i) { m1[i] = gs[2 * i]; m2[i] = gs[2 * i + 1]; }
+    }
+  }
+  constexpr int U = 4;
+  for (int p0 = ch * gm.chunk + pl; p0 < pe; p0 += U * gm.PL) {
+    float xv[U][8], sv[U][8];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int p = p0 + u * gm.PL;
+      if (p < pe) {
+        const size_t o = ((size_t)b * P + p) * C + cv * 8;
+        load8(x + o, xv[u]);
+        if (MODE == 1) load8(g + o, sv[u]);
+        else if (res) load8(res + o, sv[u]);
       }
     }
-    store8(out + o, ov);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int p = p0 + u * gm.PL;
+      if (p >= pe) continue;
+      float ov[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float xh = (xv[u][i] - mean[i]) * rstd[i];
+        if (MODE == 0) {
+          const float t = act_fwd(xh, act);
+          ov[i] = res ? t + sv[u][i] : t;
+        } else {
+          const float gh = sv[u][i] * act_bwd_from_out(xh, act);
+          ov[i] = rstd[i] * (gh - m1[i] - xh * m2[i]);
+        }
+      }
+      store8(out + ((size_t)b * P + p) * C + cv * 8, ov);
+    }
   }
 }
 
@@ -312,6 +333,82 @@ __global__ __launch_bounds__(NT) void resample_kernel(const T* x, T* y, const in
       for (int i = 0; i < 8; ++i) acc[i] += a[ty] * row[i];
     }
     store8(y + (size_t)v * 8, acc);
+  }
+}
+
+// 2x2 outputs per thread from ONE (TY+SY) x (TX+SX) input patch: neighbouring outputs of a banded
+// operator start at most SPAN source pixels apart (host-checked), so their taps overlap and the
+// per-output TN^2 loads (L1-bandwidth-bound: 36 x 16 B per output for the transposed upsample)
+// drop to a quarter of the patch.  Each patch row is reduced horizontally for both output columns as it
+// arrives, then scattered into the two output rows with the vertical weights.  Grid (x, oy/2, b):
+// no 64-bit index arithmetic.
+template <typename T, int TY, int TX, int SY, int SX>
+__global__ __launch_bounds__(NT) void resample2x2_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                         const int* __restrict__ sy,
+                                                         const float* __restrict__ wy,
+                                                         const int* __restrict__ sx,
+                                                         const float* __restrict__ wx, int H, int W,
+                                                         int Ho, int Wo, int C) {
+  constexpr int PY = TY + SY, PX = TX + SX;
+  const int CV = C / 8;
+  const int t = blockIdx.x * NT + threadIdx.x;
+  const int cv = t % CV, ox0 = (t / CV) * 2;
+  const int oy0 = blockIdx.y * 2, b = blockIdx.z;
+  if (ox0 >= Wo) return;
+  const bool has_x1 = ox0 + 1 < Wo, has_y1 = oy0 + 1 < Ho;
+  const int ox1 = has_x1 ? ox0 + 1 : ox0, oy1 = has_y1 ? oy0 + 1 : oy0;
+  const int x0 = sx[ox0], y0 = sy[oy0];
+  const int dx1 = sx[ox1] - x0, dy1 = sy[oy1] - y0;  // 0 .. SPAN
+  // weights of the two outputs re-indexed on the patch
+  float cx[2][PX], cy[2][PY];
+#pragma unroll
+  for (int k = 0; k < PX; ++k) {
+    cx[0][k] = k < TX ? wx[ox0 * TX + k] : 0.f;
+    const int kx = k - dx1;
+    cx[1][k] = (kx >= 0 && kx < TX) ? wx[ox1 * TX + kx] : 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < PY; ++k) {
+    cy[0][k] = k < TY ? wy[oy0 * TY + k] : 0.f;
+    const int ky = k - dy1;
+    cy[1][k] = (ky >= 0 && ky < TY) ? wy[oy1 * TY + ky] : 0.f;
+  }
+  const T* base = x + ((size_t)b * H * W) * C + cv * 8;
+  float acc[2][2][8];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[a][c][i] = 0.f;
+#pragma unroll
+  for (int r = 0; r < PY; ++r) {
+    const int iy = min(y0 + r, H - 1);
+    float h0[8], h1[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) h0[i] = h1[i] = 0.f;
+#pragma unroll
+    for (int k = 0; k < PX; ++k) {
+      const int ix = min(x0 + k, W - 1);
+      float v[8];
+      load8(base + ((size_t)iy * W + ix) * C, v);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { h0[i] += cx[0][k] * v[i]; h1[i] += cx[1][k] * v[i]; }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      acc[0][0][i] += cy[0][r] * h0[i];
+      acc[0][1][i] += cy[0][r] * h1[i];
+      acc[1][0][i] += cy[1][r] * h0[i];
+      acc[1][1][i] += cy[1][r] * h1[i];
+    }
+  }
+  T* o00 = y + (((size_t)b * Ho + oy0) * Wo + ox0) * C + cv * 8;
+  store8(o00, acc[0][0]);
+  if (has_x1) store8(o00 + C, acc[0][1]);
+  if (has_y1) {
+    store8(o00 + (size_t)Wo * C, acc[1][0]);
+    if (has_x1) store8(o00 + (size_t)Wo * C + C, acc[1][1]);
   }
 }
 
@@ -421,6 +518,34 @@ __global__ __launch_bounds__(NT) void modulate_weights_kernel(const float* w32, 
   }
 }
 
+// ---- kernel-side forms of an equalised-LR filter ---------------------------------------------
+// One thread per padded (o, i): walks the KK taps of the parameter (contiguous in [Co][Ci][KK]) and
+// writes W*c in the GEMM layouts: full / w_f [Cop][KK][Cip], w_d [Cip][KK reversed][Cop], and the
+// demodulation table q[o][i] = sum_kk (c W)^2 with its transpose.
+template <typename T>
+__global__ __launch_bounds__(NT) void prepare_weights_kernel(const float* w, float* full, T* w_f, T* w_d,
+                                                             float* q, float* qt, int Co, int Ci, int KK,
+                                                             int Cop, int Cip, float c) {
+  const int t = blockIdx.x * NT + threadIdx.x;
+  if (t >= Cop * Cip) return;
+  const int i = t % Cip, o = t / Cip;
+  const bool valid = o < Co && i < Ci;
+  const float* src = w + ((size_t)o * Ci + i) * KK;
+  float acc = 0.f;
+  for (int kk = 0; kk < KK; ++kk) {
+    const float v = valid ? src[kk] * c : 0.f;
+    const size_t f = ((size_t)o * KK + kk) * Cip + i;
+    full[f] = v;
+    Elem<T>::st(w_f + f, v);
+    Elem<T>::st(w_d + ((size_t)i * KK + (KK - 1 - kk)) * Cop + o, v);
+    acc += v * v;
+  }
+  if (q) {
+    q[(size_t)o * Cip + i] = acc;
+    qt[(size_t)i * Cop + o] = acc;
+  }
+}
+
 // ---- weight-gradient finalisation ----------------------------------------------------------
 // grad[o][i][kh][kw] += c * ( acc[o][kh][kw][i] + 2 * gq[o][i] * w32[o][kh][kw][i] ), then the
 // accumulators are cleared for the next backward pass.  acc is the kernel-layout fp32 buffer
@@ -480,7 +605,7 @@ inline unsigned grid_for(long n, int per_block = NT) {
 
 extern "C" {
 
-int o2m_abi_version(void) { return 5; }
+int o2m_abi_version(void) { return 8; }
 
 int o2m_modulate_weights(const float* w32, const float* s, void* out, int32_t B, int32_t Co,
                          int32_t KK, int32_t Ci, int32_t dtype, void* stream) {
@@ -489,6 +614,18 @@ int o2m_modulate_weights(const float* w32, const float* s, void* out, int32_t B,
   hipStream_t st = static_cast<hipStream_t>(stream);
   DISPATCH_T(dtype, hipLaunchKernelGGL(modulate_weights_kernel<T>, dim3(grid_for(per), B), dim3(NT), 0, st,
                                        w32, s, (T*)out, per, Ci));
+  O2M_LAUNCH_CHECK();
+  return 0;
+}
+
+int o2m_prepare_weights(const float* w, float* full, void* w_f, void* w_d, float* q, float* qt,
+                        int32_t Co, int32_t Ci, int32_t KK, int32_t Cop, int32_t Cip, float c,
+                        int32_t dtype, void* stream) {
+  if (!w || !full || !w_f || !w_d || (q == nullptr) != (qt == nullptr)) return O2M_ERR_BAD_ARG;
+  if (Co <= 0 || Ci <= 0 || KK <= 0 || Cop < Co || Cip < Ci || (Cop & 7) || (Cip & 7)) return O2M_ERR_BAD_ARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(prepare_weights_kernel<T>, dim3(grid_for((long)Cop * Cip)), dim3(NT),
+                                       0, s, w, full, (T*)w_f, (T*)w_d, q, qt, Co, Ci, KK, Cop, Cip, c));
   O2M_LAUNCH_CHECK();
   return 0;
 }
@@ -552,12 +689,12 @@ int o2m_instnorm_stats(const void* x, float* partial, float* mean_rstd, int32_t 
 int o2m_instnorm_apply(const void* x, const float* mean_rstd, const void* residual, void* y,
                        int32_t B, int32_t P, int32_t C, int32_t act, int32_t dtype, void* stream) {
   if (!x || !mean_rstd || !y || B <= 0 || P <= 0 || C <= 0 || (C & 7)) return O2M_ERR_BAD_ARG;
-  const long nvec = (long)B * P * (C / 8);
+  if (C > 8 * NT) return O2M_ERR_BAD_ARG;
+  ChanGeom gm = chan_geom(B, P, C);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  DISPATCH_T(dtype, hipLaunchKernelGGL((in_apply_kernel<T, 0>), dim3(grid_for(nvec)), dim3(NT), 0, s,
+  DISPATCH_T(dtype, hipLaunchKernelGGL((in_apply_kernel<T, 0>), dim3(gm.nchunks, B), dim3(NT), 0, s,
                                        (const T*)x, (const T*)nullptr, mean_rstd,
-                                       (const float*)nullptr, (const T*)residual, (T*)y, P, C, act,
-                                       nvec));
+                                       (const float*)nullptr, (const T*)residual, (T*)y, P, C, act, gm));
   O2M_LAUNCH_CHECK();
   return 0;
 }
@@ -570,15 +707,14 @@ int o2m_instnorm_bwd(const void* g, const void* x, const float* mean_rstd, float
     return O2M_ERR_BAD_ARG;
   ChanGeom gm = chan_geom(B, P, C);
   const size_t lds = (size_t)gm.PL * gm.CV * 16 * sizeof(float);
-  const long nvec = (long)B * P * (C / 8);
   hipStream_t s = static_cast<hipStream_t>(stream);
   DISPATCH_T(dtype, {
     hipLaunchKernelGGL((in_partial_kernel<T, 1>), dim3(gm.nchunks, B), dim3(NT), lds, s, (const T*)x,
                        (const T*)g, mean_rstd, partial, P, C, act, gm);
     hipLaunchKernelGGL(in_finalize_kernel<1>, dim3((B * C + 255) / 256), dim3(256), 0, s, partial,
                        gsums, B, P, C, gm.nchunks, 0.f);
-    hipLaunchKernelGGL((in_apply_kernel<T, 1>), dim3(grid_for(nvec)), dim3(NT), 0, s, (const T*)x,
-                       (const T*)g, mean_rstd, gsums, (const T*)nullptr, (T*)gx, P, C, act, nvec);
+    hipLaunchKernelGGL((in_apply_kernel<T, 1>), dim3(gm.nchunks, B), dim3(NT), 0, s, (const T*)x,
+                       (const T*)g, mean_rstd, gsums, (const T*)nullptr, (T*)gx, P, C, act, gm);
   });
   O2M_LAUNCH_CHECK();
   return 0;
@@ -586,12 +722,31 @@ int o2m_instnorm_bwd(const void* g, const void* x, const float* mean_rstd, float
 
 int o2m_resample2d(const void* x, void* y, const int32_t* sy, const float* wy, const int32_t* sx,
                    const float* wx, int32_t B, int32_t H, int32_t W, int32_t Ho, int32_t Wo,
-                   int32_t C, int32_t T_, int32_t dtype, void* stream) {
+                   int32_t C, int32_t Ty, int32_t Tx, int32_t span_y, int32_t span_x, int32_t dtype,
+                   void* stream) {
   if (!x || !y || !sy || !wy || !sx || !wx) return O2M_ERR_BAD_ARG;
-  if (B <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || (C & 7) || T_ <= 0)
+  if (B <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || (C & 7) || Ty <= 0 || Tx <= 0)
     return O2M_ERR_BAD_ARG;
   const long nvec = (long)B * Ho * Wo * (C / 8);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  // 2x2-block kernel for the operators the model uses; anything else takes the per-output kernel
+  if (span_y >= 1 && span_x >= 1 && B <= 65535 && (Ho + 1) / 2 <= 65535) {
+    const dim3 grid((unsigned)((((long)(Wo + 1) / 2) * (C / 8) + NT - 1) / NT), (unsigned)((Ho + 1) / 2), (unsigned)B);
+#define O2M_RESAMPLE_2X2(TY, TX, SY, SX)                                                           \
+    if (Ty == TY && Tx == TX && span_y == SY && span_x == SX) {                                    \
+      DISPATCH_T(dtype, hipLaunchKernelGGL((resample2x2_kernel<T, TY, TX, SY, SX>), grid, dim3(NT), 0, s, \
+                                           (const T*)x, (T*)y, sy, wy, sx, wx, H, W, Ho, Wo, C));  \
+      O2M_LAUNCH_CHECK();                                                                          \
+      return 0;                                                                                    \
+    }
+    O2M_RESAMPLE_2X2(2, 2, 1, 1) O2M_RESAMPLE_2X2(3, 3, 1, 1) O2M_RESAMPLE_2X2(4, 4, 2, 2)
+    O2M_RESAMPLE_2X2(4, 4, 3, 3) O2M_RESAMPLE_2X2(4, 4, 2, 3) O2M_RESAMPLE_2X2(4, 4, 3, 2)
+    // one axis at a time (the transposed upsample runs as a vertical and a horizontal pass)
+    O2M_RESAMPLE_2X2(6, 1, 2, 1) O2M_RESAMPLE_2X2(1, 6, 1, 2)
+#undef O2M_RESAMPLE_2X2
+  }
+  if (Ty != Tx) return O2M_ERR_UNSUPPORTED;
+  const int T_ = Ty;
 #define O2M_RESAMPLE_CASE(TN)                                                                   \
   case TN:                                                                                       \
     DISPATCH_T(dtype, hipLaunchKernelGGL((resample_kernel<T, TN>), dim3(grid_for(nvec)), dim3(NT), 0, s, \

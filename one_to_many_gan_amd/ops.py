@@ -195,14 +195,14 @@ class PreparedWeight:
         key = (w._version, w.data_ptr(), _STATE["epoch"], compute_dtype())
         if key != self._key:
             with torch.no_grad():
-                ws = (w.detach().float() * self.c).permute(0, 2, 3, 1)  # [co,kh,kw,ci]
-                full = torch.zeros((self.cop, self.kh, self.kw, self.cip), dtype=torch.float32,
-                                   device=w.device)
-                full[: self.co, :, :, : self.ci] = ws
-                w_f = full.to(compute_dtype()).contiguous()
-                w_d = full.flip(1, 2).permute(3, 1, 2, 0).to(compute_dtype()).contiguous()
-                q = full.square().sum(dim=(1, 2)).contiguous() if self.need_q else None
-                qt = q.t().contiguous() if self.need_q else None
+                wsrc = w.detach().float().contiguous()  # no-ops for the fp32 parameters
+                dev, cd = w.device, compute_dtype()
+                full = torch.empty((self.cop, self.kh, self.kw, self.cip), dtype=torch.float32, device=dev)
+                w_f = torch.empty((self.cop, self.kh, self.kw, self.cip), dtype=cd, device=dev)
+                w_d = torch.empty((self.cip, self.kh, self.kw, self.cop), dtype=cd, device=dev)
+                q = torch.empty((self.cop, self.cip), dtype=torch.float32, device=dev) if self.need_q else None
+                qt = torch.empty((self.cip, self.cop), dtype=torch.float32, device=dev) if self.need_q else None
+                H.prepare_weights(wsrc, full, w_f, w_d, q, qt, self.c)  # one launch per layer and step
             self._val = (w_f, w_d, q, full, qt)
             self._key = key
         return self._val
@@ -297,8 +297,11 @@ class _ConvFn(torch.autograd.Function):
                         prep.ci, 1.0 / math.sqrt(wv.shape[1]), eps)
         bias_p = None
         if bias is not None:
-            bias_p = torch.zeros(prep.cop, dtype=torch.float32, device=x.device)
-            bias_p[: prep.co] = bias.detach().float()
+            if prep.cop == prep.co and bias.dtype == torch.float32:
+                bias_p = bias.detach()
+            else:
+                bias_p = torch.zeros(prep.cop, dtype=torch.float32, device=x.device)
+                bias_p[: prep.co] = bias.detach().float()
         y = torch.empty((B, ho, wo, prep.cop), dtype=x.dtype, device=x.device)
         if s is None and residual is None and prep.s2d_ok(pad, pad_mode, Hh, Ww):
             # image conv with 3 (1) real outputs: 4x4 output pixels per GEMM row
@@ -340,10 +343,16 @@ class _ConvFn(torch.autograd.Function):
         need_res = ctx.needs_input_grad[6]
         dev = g.device
 
-        sums = None
+        sums = dots = None
+        want_sums = act != H.ACT_NONE or d is not None or (ctx.has_bias and need_b)
+        want_dots = s is not None and (need_x or need_s or (need_w and d is not None))
+        if want_sums or want_dots:  # one zero-fill for both atomically accumulated tables
+            ns, nd = (B * 2 * prep.cop if want_sums else 0), (B * cip if want_dots else 0)
+            z = torch.zeros(ns + nd, dtype=torch.float32, device=dev)
+            sums = z[:ns].view(B, 2, prep.cop) if want_sums else None
+            dots = z[ns:].view(B, cip) if want_dots else None
         if act != H.ACT_NONE or d is not None:
             gu = torch.empty_like(g)
-            sums = torch.zeros((B, 2, prep.cop), dtype=torch.float32, device=dev)
             # u = y - residual = act(pre); the stored tensor is gu * d (demodulation folded in)
             H.act_bwd_reduce(g, y, residual, d, gu, sums, act)
         else:
@@ -351,13 +360,12 @@ class _ConvFn(torch.autograd.Function):
 
         g_bias = None
         if ctx.has_bias and need_b:
-            if sums is None:  # no activation: reduce-only pass over g (one read, nothing stored)
-                sums = torch.zeros((B, 2, prep.cop), dtype=torch.float32, device=dev)
+            if act == H.ACT_NONE and d is None:  # reduce-only pass over g (one read, nothing stored)
                 H.act_bwd_reduce(g, None, None, None, None, sums, H.ACT_NONE)
             tot = sums[:, 0].sum(0)
             g_bias = tot[: prep.co].to(weight.dtype)
 
-        g_x = dots = xs = None
+        g_x = xs = None
         if need_x or need_s:
             kpad = prep.kh - 1 - (0 if pad_mode == H.PAD_REFLECT else pad)
             hp = Hh + (2 * pad if pad_mode == H.PAD_REFLECT else 0)
@@ -367,7 +375,6 @@ class _ConvFn(torch.autograd.Function):
             if s is not None or pad_mode == H.PAD_REFLECT:
                 g_x = torch.empty_like(x)
                 if s is not None:
-                    dots = torch.zeros((B, cip), dtype=torch.float32, device=dev)
                     if need_w:  # x * s for the weight gradient, written while x is being read
                         xs = torch.empty_like(x)
                 H.fold_scale_dot(gxp, x if s is not None else None, s, g_x, dots,
@@ -392,8 +399,6 @@ class _ConvFn(torch.autograd.Function):
 
         g_ws = g_tw = g_tb = None
         if s is not None and (need_s or (need_w and d is not None)):
-            if dots is None:
-                dots = torch.zeros((B, cip), dtype=torch.float32, device=dev)
             wd_ = wv.shape[1]
             e = torch.empty((B, prep.cop), dtype=torch.float32, device=dev) if d is not None else None
             gs = torch.empty((B, cip), dtype=torch.float32, device=dev)
@@ -457,13 +462,28 @@ def instance_norm_act(x, act=H.ACT_NONE, residual=None, eps=1e-5):
 # -------------------------------------------------------------------------------- resample
 
 
+def _apply_taps(x, taps):
+    """One banded 2-D operator on an NHWC buffer.  Wide operators (the 6-tap transposed upsample:
+    36 taps per output in one pass) run as a vertical then a horizontal 1-D pass."""
+    sy, wy, sx, wx, T, ho, wo = taps
+    B, Hh, Ww, Cn = x.shape
+    y = torch.empty((B, ho, wo, Cn), dtype=x.dtype, device=x.device)
+    if int(T) == 6 and T.span_y == 2 and T.span_x == 2:  # the instantiated 1-D kernels
+        ix, iwx = R.identity_taps(Ww, x.device)
+        iy, iwy = R.identity_taps(ho, x.device)
+        mid = torch.empty((B, ho, Ww, Cn), dtype=x.dtype, device=x.device)
+        H.resample2d(x, mid, sy, wy, ix, iwx, int(T), 1, T.span_y, 1)
+        H.resample2d(mid, y, iy, iwy, sx, wx, 1, int(T), 1, T.span_x)
+    else:
+        H.resample2d(x, y, sy, wy, sx, wx, int(T), int(T), T.span_y, T.span_x)
+    return y
+
+
 class _ResampleFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, kind):
         B, Hh, Ww, Cn = x.shape
-        sy, wy, sx, wx, T, ho, wo = R.taps(kind, Hh, Ww, False, x.device)
-        y = torch.empty((B, ho, wo, Cn), dtype=x.dtype, device=x.device)
-        H.resample2d(x, y, sy, wy, sx, wx, T)
+        y = _apply_taps(x, R.taps(kind, Hh, Ww, False, x.device))
         ctx.kind, ctx.hw = kind, (Hh, Ww)
         return y
 
@@ -471,9 +491,7 @@ class _ResampleFn(torch.autograd.Function):
     def backward(ctx, g):
         g = g.contiguous()
         Hh, Ww = ctx.hw
-        sy, wy, sx, wx, T, ho, wo = R.taps(ctx.kind, Hh, Ww, True, g.device)
-        gx = torch.empty((g.shape[0], ho, wo, g.shape[3]), dtype=g.dtype, device=g.device)
-        H.resample2d(g, gx, sy, wy, sx, wx, T)
+        gx = _apply_taps(g, R.taps(ctx.kind, Hh, Ww, True, g.device))
         return gx, None
 
 

@@ -87,6 +87,38 @@ def _taps_host(kind: str, n: int, transposed: bool):
 _dev_cache: dict = {}
 
 
+class Taps(int):
+    """Tap count of a banded operator pair.  ``span_y`` / ``span_x`` = largest step between
+    consecutive tap starts of that axis when the starts are non-decreasing (lets the kernel share
+    one input patch between neighbouring outputs), else 0."""
+
+    def __new__(cls, t, span_y, span_x):
+        obj = super().__new__(cls, t)
+        obj.span_y, obj.span_x = span_y, span_x
+        return obj
+
+
+def _span(s):
+    if s.shape[0] < 2:
+        return 1
+    d = np.diff(s)
+    lo, hi = int(d.min()), int(d.max())
+    return max(hi, 1) if lo >= 0 and hi <= 3 else 0
+
+
+_id_cache: dict = {}
+
+
+def identity_taps(n: int, device):
+    """(start, weights) of the n x n identity as a 1-tap banded operator."""
+    key = (n, str(device))
+    hit = _id_cache.get(key)
+    if hit is None:
+        hit = (torch.arange(n, dtype=torch.int32, device=device), torch.ones((n, 1), dtype=torch.float32, device=device))
+        _id_cache[key] = hit
+    return hit
+
+
 def taps(kind: str, n_h: int, n_w: int, transposed: bool, device):
     """Device-resident taps for both axes, padded to a common T."""
     key = (kind, n_h, n_w, transposed, str(device))
@@ -117,7 +149,7 @@ def taps(kind: str, n_h: int, n_w: int, transposed: bool, device):
     res = (
         torch.from_numpy(sy).to(device), torch.from_numpy(np.ascontiguousarray(wy)).to(device),
         torch.from_numpy(sx).to(device), torch.from_numpy(np.ascontiguousarray(wx)).to(device),
-        T, out_h, out_w,
+        Taps(T, _span(sy), _span(sx)), out_h, out_w,
     )
     _dev_cache[key] = res
     return res
