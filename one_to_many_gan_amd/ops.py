@@ -215,6 +215,20 @@ import os as _os
 # (72.1 / 72.6 ms deferred vs 72.3 / 72.4 ms immediate, same box) while keeping every x / gy
 # alive until the end of backward, so it is off by default.
 _DEFER_WGRAD = _os.environ.get("O2M_DEFER_WGRAD", "0") == "1"
+# The style-path kernels are B x C sized: alone on the GPU they leave 250 CUs idle for 6-14 us each
+# (~110 launches per generator backward).  O2M_SIDE_STREAM=1 (default) runs them on a second HIP
+# stream, ordered by events, so they overlap the neighbouring convolution kernels.
+_SIDE_STREAM = _os.environ.get("O2M_SIDE_STREAM", "1") == "1"
+_SIDE: dict = {}
+
+
+def _side_stream(device):
+    if not _SIDE_STREAM or device.type != "cuda":
+        return None
+    st = _SIDE.get(device)
+    if st is None:
+        st = _SIDE[device] = torch.cuda.Stream(device=device)
+    return st
 _PENDING: list = []
 # parameter -> callable(param), invoked when that filter's gradient has been written by
 # _finalize_weight_grads (the data-parallel reducer counts these like autograd's own
@@ -382,6 +396,22 @@ class _ConvFn(torch.autograd.Function):
             else:
                 g_x = gxp
 
+        run_style = s is not None and (need_s or (need_w and d is not None))
+        ev_pre = None
+        if run_style:  # outputs allocated (and sums / dots complete) before the event the side stream waits on
+            wd_ = wv.shape[1]
+            e = torch.empty((B, prep.cop), dtype=torch.float32, device=dev) if d is not None else None
+            gs = torch.empty((B, cip), dtype=torch.float32, device=dev)
+            g_ws = torch.empty((B, wd_), dtype=torch.float32, device=dev)
+            g_tw = torch.empty((prep.ci, wd_), dtype=torch.float32, device=dev)
+            g_tb = torch.empty((prep.ci,), dtype=torch.float32, device=dev)
+            gq_tmp = None
+            if d is not None and not need_w:  # dL/dQ is discarded when the filter wants no gradient
+                gq_tmp = torch.zeros((prep.cop, cip), dtype=torch.float32, device=dev)
+            if _side_stream(dev) is not None:
+                ev_pre = torch.cuda.Event()
+                ev_pre.record(torch.cuda.current_stream(dev))
+
         gq_acc = None
         if need_w:
             # accumulated in the kernel layout across every use of the layer in this backward;
@@ -397,19 +427,23 @@ class _ConvFn(torch.autograd.Function):
             else:
                 H.conv2d_wgrad(x, gu, dw_acc, in_scale=s, pad=pad, pad_mode=pad_mode)
 
-        g_ws = g_tw = g_tb = None
-        if s is not None and (need_s or (need_w and d is not None)):
-            wd_ = wv.shape[1]
-            e = torch.empty((B, prep.cop), dtype=torch.float32, device=dev) if d is not None else None
-            gs = torch.empty((B, cip), dtype=torch.float32, device=dev)
-            g_ws = torch.empty((B, wd_), dtype=torch.float32, device=dev)
-            g_tw = torch.empty((prep.ci, wd_), dtype=torch.float32, device=dev)
-            g_tb = torch.empty((prep.ci,), dtype=torch.float32, device=dev)
-            gq = None
-            if d is not None:  # dL/dQ: kept only if the filter wants a gradient
-                gq = gq_acc if gq_acc is not None else torch.zeros((prep.cop, cip), dtype=torch.float32, device=dev)
-            H.style_bwd(sums, bias_p, dots, s, d, q, wv, ws, e, gs, g_ws, g_tw, g_tb, gq, prep.ci,
-                        1.0 / math.sqrt(wd_))
+        if run_style:
+            gq = (gq_acc if gq_acc is not None else gq_tmp) if d is not None else None
+            side = _side_stream(dev)
+            if side is not None:  # overlaps the weight-gradient kernel enqueued just above
+                main = torch.cuda.current_stream(dev)
+                side.wait_event(ev_pre)
+                with torch.cuda.stream(side):
+                    H.style_bwd(sums, bias_p, dots, s, d, q, wv, ws, e, gs, g_ws, g_tw, g_tb, gq, prep.ci,
+                                1.0 / math.sqrt(wd_))
+                    ev_done = torch.cuda.Event()
+                    ev_done.record(side)
+                main.wait_event(ev_done)
+            else:
+                H.style_bwd(sums, bias_p, dots, s, d, q, wv, ws, e, gs, g_ws, g_tw, g_tb, gq, prep.ci,
+                            1.0 / math.sqrt(wd_))
+        else:
+            g_ws = g_tw = g_tb = None
         g_res = g if (ctx.has_res and need_res) else None
         return (g_x if need_x else None, None, g_bias, g_ws, g_tw, g_tb, g_res,
                 None, None, None, None, None, None)
