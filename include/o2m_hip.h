@@ -227,6 +227,21 @@ int o2m_resample2d(const void* x, void* y, const int32_t* sy, const float* wy,
                    int32_t span_x, int32_t dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Device-resident input pipeline: the reference keeps every image in
+ * host RAM as a normalised float tensor (datasets.py:34-42), flips it per fetch
+ * (datasets.py:44-50) and ships batches through 3 x 8 DataLoader workers + pinned H2D copies
+ * (train.py:128-165).  Here the images stay in HBM as uint8 NHWC; one launch builds a batch:
+ *   out[b][y][x][c] = ((pool[index[b]][y][flip[b] ? W-1-x : x][c] / 255) - 0.5) / 0.5
+ * = ToTensor + Normalize((0.5,), (0.5,)) (train.py:120-126) + RandomHorizontalFlip, evaluated
+ * in fp32 in that order, then stored as `dtype` with channels C..Cp-1 zeroed.
+ * pool: uint8 [N][H][W][C]; index: int32 [B] (no range check on the device: the host
+ * guarantees 0 <= index[b] < N); flip: uint8 [B]; out: `dtype` [B][H][W][Cp].
+ */
+int o2m_gather_images(const uint8_t* pool, const int32_t* index, const uint8_t* flip, void* out,
+                      int32_t N, int32_t B, int32_t H, int32_t W, int32_t C, int32_t Cp,
+                      int32_t dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Layout conversion at the public (logical NCHW fp32) boundary.
  *   pack  : NCHW fp32 [B][C][H][W]  -> NHWC `dtype` [B][H][W][Cp] (channels >= C zeroed)
  *   unpack: NHWC `dtype` [B][H][W][Cp] -> NCHW fp32 [B][C][H][W]

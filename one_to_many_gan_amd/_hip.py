@@ -20,7 +20,7 @@ BF16, F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 PAD_ZERO, PAD_REFLECT = 0, 1
 RED_L1, RED_SQ, RED_MOM = 0, 1, 2
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -59,6 +59,7 @@ SIGNATURES = {
     "o2m_instnorm_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "o2m_resample2d": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                               _i32, _i32, _i32, _i32, _vp]),
+    "o2m_gather_images": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "o2m_pack_nchw": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "o2m_unpack_nhwc": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "o2m_reduce_blocks": (_i32, [_i64]),
@@ -96,10 +97,16 @@ def _igemm_name(dt, co, scaled, m=1 << 30, k=1 << 30):
     return f"conv_igemm<{t},{tile},in_scale={int(scaled)}>"
 
 
-def _wgrad_name(dt, co):
+def _wgrad_name(dt, co, m=0, k=0):
+    """Mirrors launch_dtype() in csrc/conv_wgrad.hip."""
     t = "bf16" if dt == torch.bfloat16 else "f32x3"
-    tile = "128" if co > 64 else ("64" if co > 32 else "32")
-    return f"conv_wgrad<{t},co{tile}xk128>"
+    if co > 256 or (co > 128 and m >= 100000):
+        tile = "co256xk128"
+    elif 64 < co <= 128 and k % 256 == 0 and dt == torch.bfloat16:
+        tile = "co128xk256"
+    else:
+        tile = ("co128" if co > 64 else ("co64" if co > 32 else "co32")) + "xk128"
+    return f"conv_wgrad<{t},{tile}>"
 
 
 def _timed(name, flops, tensor, launch):
@@ -188,7 +195,7 @@ def conv2d_wgrad(x, gy, dw, *, in_scale=None, gy_scale=None, pad, pad_mode, spli
         d.x_seg[i], d.gy_seg[i] = xi.data_ptr(), gi.data_ptr()
         ptr(xi), ptr(gi)  # contiguity / device checks
     flops = 2.0 * (1 + len(more)) * gy.shape[0] * gy.shape[1] * gy.shape[2] * Co * KH * KW * Ci
-    _timed(_wgrad_name(x.dtype, Co), flops, x,
+    _timed(_wgrad_name(x.dtype, Co, (1 + len(more)) * gy.shape[0] * gy.shape[1] * gy.shape[2], KH * KW * Ci), flops, x,
            lambda: check(lib().o2m_conv2d_wgrad(C.byref(d), _stream(x)), "o2m_conv2d_wgrad"))
 
 
@@ -271,6 +278,18 @@ def resample2d(x, y, sy, wy, sx, wx, ty, tx=None, span_y=0, span_x=0):
     tx = ty if tx is None else tx
     check(lib().o2m_resample2d(ptr(x), ptr(y), ptr(sy), ptr(wy), ptr(sx), ptr(wx), B, H, W, Ho, Wo, Cn,
                                ty, tx, span_y, span_x, dtype_code(x.dtype), _stream(x)), "o2m_resample2d")
+
+
+def gather_images(pool, index, flip, out):
+    """Batch from the HBM-resident uint8 pool (see o2m_gather_images)."""
+    N, H, W, Cn = pool.shape
+    B, _, _, Cp = out.shape
+    if pool.dtype != torch.uint8 or index.dtype != torch.int32 or flip.dtype != torch.uint8:
+        raise RuntimeError("gather_images: pool uint8, index int32, flip uint8")
+    if index.shape[0] != B or flip.shape[0] != B or out.shape[1:3] != pool.shape[1:3]:
+        raise RuntimeError("gather_images: shape mismatch")
+    check(lib().o2m_gather_images(ptr(pool), ptr(index), ptr(flip), ptr(out), N, B, H, W, Cn, Cp,
+                                  dtype_code(out.dtype), _stream(out)), "o2m_gather_images")
 
 
 def pack_nchw(src, dst):

@@ -47,10 +47,11 @@ __device__ __forceinline__ void lanes_reduce(float (&v)[NV], int cv, int pl, int
 
 // ---- act backward + per-(b,c) sums --------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(NT) void act_bwd_reduce_kernel(const T* g, const T* y, const T* res,
-                                                            const float* out_mul, T* gu,
-                                                            float* sums, int P, int C, int act,
-                                                            ChanGeom gm) {
+__global__ __launch_bounds__(NT) void act_bwd_reduce_kernel(const T* __restrict__ g, const T* __restrict__ y,
+                                                            const T* __restrict__ res,
+                                                            const float* __restrict__ out_mul,
+                                                            T* __restrict__ gu, float* __restrict__ sums,
+                                                            int P, int C, int act, ChanGeom gm) {
   extern __shared__ float sm[];
   const int b = blockIdx.y, ch = blockIdx.x;
   const int cv = threadIdx.x % gm.CV, pl = threadIdx.x / gm.CV;
@@ -61,6 +62,7 @@ __global__ __launch_bounds__(NT) void act_bwd_reduce_kernel(const T* g, const T*
 #pragma unroll
   for (int i = 0; i < 8; ++i) mul[i] = out_mul ? out_mul[(size_t)b * C + cv * 8 + i] : 1.f;
   if (pl < gm.PL) {
+#pragma unroll 4
     for (int p = ch * gm.chunk + pl; p < pe; p += gm.PL) {
       const size_t o = ((size_t)b * P + p) * C + cv * 8;
       float gv[8], yv[8], rv[8], ov[8];
@@ -92,9 +94,10 @@ __global__ __launch_bounds__(NT) void act_bwd_reduce_kernel(const T* g, const T*
 
 // ---- reflect-pad backward (fold) + style scale + style dot ----------------------------------
 template <typename T>
-__global__ __launch_bounds__(NT) void fold_scale_dot_kernel(const T* gpad, const T* x,
-                                                            const float* scale, T* gx,
-                                                            float* dots, T* xmod, int H, int W, int C,
+__global__ __launch_bounds__(NT) void fold_scale_dot_kernel(const T* __restrict__ gpad, const T* __restrict__ x,
+                                                            const float* __restrict__ scale,
+                                                            T* __restrict__ gx, float* __restrict__ dots,
+                                                            T* __restrict__ xmod, int H, int W, int C,
                                                             int pad, ChanGeom gm) {
   extern __shared__ float sm[];
   const int b = blockIdx.y, ch = blockIdx.x;
@@ -108,6 +111,7 @@ __global__ __launch_bounds__(NT) void fold_scale_dot_kernel(const T* gpad, const
 #pragma unroll
   for (int i = 0; i < 8; ++i) sc[i] = scale ? scale[(size_t)b * C + cv * 8 + i] : 1.f;
   if (pl < gm.PL) {
+#pragma unroll 2
     for (int p = ch * gm.chunk + pl; p < pe; p += gm.PL) {
       const int yy = p / W, xx = p - yy * W;
       int ys[3], xs[3], ny = 0, nx = 0;
@@ -158,8 +162,9 @@ __global__ __launch_bounds__(NT) void fold_scale_dot_kernel(const T* gpad, const
 // ---- instance norm ---------------------------------------------------------------------------
 // MODE 0: {sum x, sum x^2};  MODE 1 (backward): {sum gh, sum gh*xh}
 template <typename T, int MODE>
-__global__ __launch_bounds__(NT) void in_partial_kernel(const T* x, const T* g,
-                                                        const float* mean_rstd, float* partial,
+__global__ __launch_bounds__(NT) void in_partial_kernel(const T* __restrict__ x, const T* __restrict__ g,
+                                                        const float* __restrict__ mean_rstd,
+                                                        float* __restrict__ partial,
                                                         int P, int C, int act, ChanGeom gm) {
   extern __shared__ float sm[];
   const int b = blockIdx.y, ch = blockIdx.x;
@@ -177,6 +182,7 @@ __global__ __launch_bounds__(NT) void in_partial_kernel(const T* x, const T* g,
     }
   }
   if (pl < gm.PL) {
+#pragma unroll 4
     for (int p = ch * gm.chunk + pl; p < pe; p += gm.PL) {
       const size_t o = ((size_t)b * P + p) * C + cv * 8;
       float xv[8];
@@ -412,6 +418,31 @@ __global__ __launch_bounds__(NT) void resample2x2_kernel(const T* __restrict__ x
   }
 }
 
+// ---- device-resident image pool -> training batch ----------------------------------------------
+// out[b][y][x][c] = ((pool[idx[b]][y][flip[b] ? W-1-x : x][c] / 255) - 0.5) / 0.5   (c < C; else 0)
+// i.e. ToTensor + Normalize(0.5, 0.5) + RandomHorizontalFlip of the reference's input pipeline
+// (train.py:120-126, datasets.py:44-50) in fp32, in the order the reference applies them, on uint8
+// images that never leave HBM.  One thread per output pixel (all Cp channels: C is 1 or 3).
+template <typename T>
+__global__ __launch_bounds__(NT) void gather_images_kernel(const unsigned char* __restrict__ pool,
+                                                           const int* __restrict__ idx,
+                                                           const unsigned char* __restrict__ flip,
+                                                           T* __restrict__ out, int H, int W, int C, int Cp) {
+  const int b = blockIdx.z, y = blockIdx.y;
+  const int x = blockIdx.x * NT + threadIdx.x;
+  if (x >= W) return;
+  const int sx = flip[b] ? W - 1 - x : x;
+  const unsigned char* src = pool + (((size_t)idx[b] * H + y) * W + sx) * C;
+  T* dst = out + (((size_t)b * H + y) * W + x) * Cp;
+  for (int c0 = 0; c0 < Cp; c0 += 8) {
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      v[k] = (c0 + k) < C ? ((float)src[c0 + k] / 255.f - 0.5f) / 0.5f : 0.f;
+    store8(dst + c0, v);
+  }
+}
+
 // ---- NCHW fp32 <-> NHWC (channel padded) ----------------------------------------------------
 template <typename T>
 __global__ void pack_kernel(const float* src, T* dst, int C, int HW, int Cp, long npix) {
@@ -605,7 +636,7 @@ inline unsigned grid_for(long n, int per_block = NT) {
 
 extern "C" {
 
-int o2m_abi_version(void) { return 8; }
+int o2m_abi_version(void) { return 9; }
 
 int o2m_modulate_weights(const float* w32, const float* s, void* out, int32_t B, int32_t Co,
                          int32_t KK, int32_t Ci, int32_t dtype, void* stream) {
@@ -758,6 +789,20 @@ int o2m_resample2d(const void* x, void* y, const int32_t* sy, const float* wy, c
     default: return O2M_ERR_UNSUPPORTED;
   }
 #undef O2M_RESAMPLE_CASE
+  O2M_LAUNCH_CHECK();
+  return 0;
+}
+
+int o2m_gather_images(const uint8_t* pool, const int32_t* index, const uint8_t* flip, void* out,
+                      int32_t N, int32_t B, int32_t H, int32_t W, int32_t C, int32_t Cp, int32_t dtype,
+                      void* stream) {
+  if (!pool || !index || !flip || !out) return O2M_ERR_BAD_ARG;
+  if (N <= 0 || B <= 0 || H <= 0 || W <= 0 || C <= 0 || Cp < C || (Cp & 7)) return O2M_ERR_BAD_ARG;
+  if (B > 65535 || H > 65535) return O2M_ERR_UNSUPPORTED;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)((W + NT - 1) / NT), (unsigned)H, (unsigned)B);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(gather_images_kernel<T>, grid, dim3(NT), 0, s, pool, index, flip,
+                                       (T*)out, H, W, C, Cp));
   O2M_LAUNCH_CHECK();
   return 0;
 }

@@ -6,7 +6,8 @@ matplotlib grids, the author's image folders).
   python train.py config.toml [--steps N] [--synthetic] [--resume ckpt.tar] [--precision bf16|fp32]
 
 Data: ``--synthetic`` (default when the configured directories do not exist) draws
-uniform [-1, 1) images resident in HBM, as bench.py does.  Real data: any iterator of
+uniform [-1, 1) images resident in HBM, as bench.py does.  Real data: image folders through the
+device-resident pool of one_to_many_gan_amd/data/datasets.py, or any iterator of
 (B, C, H, W) tensors can be handed to ``run``.
 """
 
@@ -116,11 +117,21 @@ def main(argv=None):
     device = torch.device(f"cuda:{config['training']['gpu_number']}")
     o2m.set_precision(args.precision)
     have_data = config["data"]["shoeprint_data_dir"].exists() and config["data"]["shoemark_data_dir"].exists()
-    if not (args.synthetic or not have_data):
-        sys.exit("image-folder datasets are outside the built hot path: pass --synthetic or hand iterators to run()")
     steps = args.steps if args.steps is not None else config["training"]["training_steps"]
-    run(config, device, steps, synthetic_batches(1000, config, device), synthetic_batches(2000, config, device),
-        resume=args.resume)
+    if args.synthetic or not have_data:
+        prints, marks = synthetic_batches(1000, config, device), synthetic_batches(2000, config, device)
+    else:
+        # reference train.py:118-169 with the images resident in HBM (data/datasets.py)
+        from one_to_many_gan_amd.data import datasets as D
+
+        tf = D.Compose([D.Resize(tuple(config["data"]["image_size"])), D.ToTensor(), D.Normalize((0.5,), (0.5,))])
+        g = torch.Generator().manual_seed(config["training"]["random_seed"])
+        loaders = []
+        for key in ("shoeprint_data_dir", "shoemark_data_dir"):
+            pool = D.DeviceImagePool(D.ShoeDataset(config["data"][key], mode="train", transform=tf), device)
+            loaders.append(D.DeviceLoader(pool, config["training"]["batch_size"], generator=g))
+        prints, marks = loaders[0].cycle(), loaders[1].cycle()
+    run(config, device, steps, prints, marks, resume=args.resume)
 
 
 if __name__ == "__main__":
