@@ -41,3 +41,37 @@ def test_train_loop_checkpoint_and_resume(tmp_path):
 
     g = om.Generator(1, 6, (64, 64), 64, 7)
     g.load_state_dict(blob["generator_state_dict"])
+
+
+def test_train_loop_on_image_folders(tmp_path):
+    """The reference's data path (train.py:118-169): image folders -> ShoeDataset -> HBM pool ->
+    DeviceLoader.cycle() -> step functions, two steps at 64x64x1 with 6 + 5 PNG / JPG files."""
+    import numpy as np
+    from PIL import Image
+
+    import train
+    import one_to_many_gan_amd as o2m
+    from one_to_many_gan_amd.data import datasets as D
+    from tests.cases import make_config
+
+    o2m.set_precision("bf16")
+    rng = np.random.default_rng(3)
+    for name, n in (("prints", 6), ("marks", 5)):
+        d = tmp_path / name / "train"
+        d.mkdir(parents=True)
+        for i in range(n):
+            Image.fromarray(rng.integers(0, 256, size=(80, 72), dtype=np.uint8)).save(d / f"{i}.{'png' if i % 2 else 'jpg'}")
+    cfg = make_config(1, (64, 64), 4)
+    cfg["training"].update(checkpoint_directory=tmp_path, training_run="f", training_steps=2)
+    cfg["evaluation"] = {"log_interval": 1, "checkpoint_interval": 100, "n_evaluation_images": 0,
+                         "inference_batch_size": 4}
+    dev = torch.device("cuda:0")
+    tf = D.Compose([D.Resize((64, 64)), D.ToTensor(), D.Normalize((0.5,), (0.5,))])
+    g = torch.Generator().manual_seed(0)
+    loaders = [D.DeviceLoader(D.DeviceImagePool(D.ShoeDataset(tmp_path / k, mode="train", transform=tf), dev), 4,
+                              generator=g) for k in ("prints", "marks")]
+    assert len(loaders[0]) == 1 and len(loaders[1]) == 1  # drop_last
+    lines = []
+    train.run(cfg, dev, 2, loaders[0].cycle(), loaders[1].cycle(), log=lines.append)
+    assert any(l.startswith("[2/2]") for l in lines)
+    assert all("nan" not in l.lower() for l in lines)
