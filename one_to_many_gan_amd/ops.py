@@ -10,6 +10,7 @@ module API (builder.py) is met without copies.
 
 from __future__ import annotations
 
+import contextlib
 import math
 
 import torch
@@ -222,6 +223,22 @@ _SIDE_STREAM = _os.environ.get("O2M_SIDE_STREAM", "1") == "1"
 _SIDE: dict = {}
 
 
+# O2M_WGRAD_STREAM=1: the weight-gradient reductions are off the critical path of backward (only
+# _finalize_weight_grads needs them), so they can run on their own stream next to the HBM-bound
+# pointwise kernels of the following layers.
+_WGRAD_STREAM = _os.environ.get("O2M_WGRAD_STREAM", "0") == "1"
+_WSTREAM: dict = {}
+
+
+def _wgrad_stream(device):
+    if not _WGRAD_STREAM or device.type != "cuda":
+        return None
+    st = _WSTREAM.get(device)
+    if st is None:
+        st = _WSTREAM[device] = torch.cuda.Stream(device=device)
+    return st
+
+
 def _side_stream(device):
     if not _SIDE_STREAM or device.type != "cuda":
         return None
@@ -256,6 +273,8 @@ def _finalize_weight_grads():
     kernel-layout gradient into ``weight.grad``."""
     pend = list(_PENDING)
     _PENDING.clear()
+    for dev, wst in _WSTREAM.items():  # weight gradients reduced on their own stream
+        torch.cuda.current_stream(dev).wait_stream(wst)
     for prep in pend:
         prep.pending = False
         if prep.uses:
@@ -418,14 +437,23 @@ class _ConvFn(torch.autograd.Function):
             # converted into weight.grad once, by _finalize_weight_grads
             dw_acc, gq_acc = prep.accumulators(dev)
             x_eff = xs if xs is not None else (x if s is None else None)
-            if s is None and residual is None and prep.s2d_ok(pad, pad_mode, Hh, Ww):
-                prep.s2d_wgrad(x, gu, pad, pad_mode)
-            elif _DEFER_WGRAD and x_eff is not None and gu.shape[2] % 32 == 0:
-                prep.uses.append((x_eff, gu, pad, pad_mode))  # reduced at the end of backward
-            elif x_eff is not None:
-                H.conv2d_wgrad(x_eff, gu, dw_acc, pad=pad, pad_mode=pad_mode)
-            else:
-                H.conv2d_wgrad(x, gu, dw_acc, in_scale=s, pad=pad, pad_mode=pad_mode)
+            wst = _wgrad_stream(dev)
+            if wst is not None:
+                ev_w = torch.cuda.Event()
+                ev_w.record(torch.cuda.current_stream(dev))
+                wst.wait_event(ev_w)
+                for t in (x, x_eff, gu, s):  # keep the operands alive until the side stream is done
+                    if t is not None:
+                        t.record_stream(wst)
+            with (torch.cuda.stream(wst) if wst is not None else contextlib.nullcontext()):
+                if s is None and residual is None and prep.s2d_ok(pad, pad_mode, Hh, Ww):
+                    prep.s2d_wgrad(x, gu, pad, pad_mode)
+                elif _DEFER_WGRAD and x_eff is not None and gu.shape[2] % 32 == 0:
+                    prep.uses.append((x_eff, gu, pad, pad_mode))  # reduced at the end of backward
+                elif x_eff is not None:
+                    H.conv2d_wgrad(x_eff, gu, dw_acc, pad=pad, pad_mode=pad_mode)
+                else:
+                    H.conv2d_wgrad(x, gu, dw_acc, in_scale=s, pad=pad, pad_mode=pad_mode)
 
         if run_style:
             gq = (gq_acc if gq_acc is not None else gq_tmp) if d is not None else None
