@@ -242,6 +242,36 @@ int o2m_gather_images(const uint8_t* pool, const int32_t* index, const uint8_t* 
                       int32_t dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Adaptive discriminator augmentation (reference call sites train.py:175-188,
+ * training.py:100,104,200; the transforms live in the un-vendored dependency pytorch-ada, so
+ * these follow the published StyleGAN2-ADA pipe -- see one_to_many_gan_amd/ada.py, oracle/ada.py;
+ * parity unpinned).  Images are NHWC with Cp (multiple of 8) stored channels, C (1 or 3) real.
+ *
+ * o2m_ada_grid_sample: F.affine_grid(theta, align_corners=False) + F.grid_sample(bilinear,
+ *   zeros padding, align_corners=False) of x [B][Hs][Ws][Cp] into y [B][Ho][Wo][Cp];
+ *   theta fp32 [B][2][3] in normalised coordinates.
+ * o2m_ada_grid_sample_bwd: its adjoint; gx fp32 [B][Hs][Ws][Cp], ZEROED by the caller, receives
+ *   atomic adds for the C real channels.
+ * o2m_reflect_fold: adjoint of F.pad(mode="reflect") with margins (pad_left, Wp-W-pad_left,
+ *   pad_top, Hp-H-pad_top), each smaller than the image; gpad [B][Hp][Wp][Cp] (in_dtype) ->
+ *   gx [B][H][W][Cp] (out_dtype).
+ * o2m_ada_colour: y[c] = sum_k m[b][c][k] x[k] + m[b][c][3] on the C real channels
+ *   (m fp32 [B][3][4]; C = 1 uses m[b][0][0] and m[b][0][3]); padding channels written as 0.
+ *   P = pixels per sample.  Its adjoint is the same call with the transposed matrix and zero
+ *   offsets.
+ */
+int o2m_ada_grid_sample(const void* x, const float* theta, void* y, int32_t B, int32_t Hs,
+                        int32_t Ws, int32_t Ho, int32_t Wo, int32_t Cp, int32_t dtype, void* stream);
+int o2m_ada_grid_sample_bwd(const void* gy, const float* theta, float* gx, int32_t B, int32_t Hs,
+                            int32_t Ws, int32_t Ho, int32_t Wo, int32_t C, int32_t Cp,
+                            int32_t dtype, void* stream);
+int o2m_reflect_fold(const void* gpad, void* gx, int32_t B, int32_t H, int32_t W, int32_t Hp,
+                     int32_t Wp, int32_t pad_top, int32_t pad_left, int32_t Cp, int32_t in_dtype,
+                     int32_t out_dtype, void* stream);
+int o2m_ada_colour(const void* x, const float* m, void* y, int32_t B, int64_t P, int32_t C,
+                   int32_t Cp, int32_t dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Layout conversion at the public (logical NCHW fp32) boundary.
  *   pack  : NCHW fp32 [B][C][H][W]  -> NHWC `dtype` [B][H][W][Cp] (channels >= C zeroed)
  *   unpack: NHWC `dtype` [B][H][W][Cp] -> NCHW fp32 [B][C][H][W]

@@ -20,7 +20,7 @@ BF16, F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 PAD_ZERO, PAD_REFLECT = 0, 1
 RED_L1, RED_SQ, RED_MOM = 0, 1, 2
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -59,6 +59,10 @@ SIGNATURES = {
     "o2m_instnorm_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "o2m_resample2d": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                               _i32, _i32, _i32, _i32, _vp]),
+    "o2m_ada_grid_sample": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "o2m_ada_grid_sample_bwd": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "o2m_reflect_fold": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "o2m_ada_colour": (_i32, [_vp, _vp, _vp, _i32, C.c_int64, _i32, _i32, _i32, _vp]),
     "o2m_gather_images": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "o2m_pack_nchw": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "o2m_unpack_nhwc": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
@@ -278,6 +282,35 @@ def resample2d(x, y, sy, wy, sx, wx, ty, tx=None, span_y=0, span_x=0):
     tx = ty if tx is None else tx
     check(lib().o2m_resample2d(ptr(x), ptr(y), ptr(sy), ptr(wy), ptr(sx), ptr(wx), B, H, W, Ho, Wo, Cn,
                                ty, tx, span_y, span_x, dtype_code(x.dtype), _stream(x)), "o2m_resample2d")
+
+
+def ada_grid_sample(x, theta, y):
+    B, Hs, Ws, Cp = x.shape
+    _, Ho, Wo, _ = y.shape
+    check(lib().o2m_ada_grid_sample(ptr(x), ptr(theta), ptr(y), B, Hs, Ws, Ho, Wo, Cp, dtype_code(x.dtype),
+                                    _stream(x)), "o2m_ada_grid_sample")
+
+
+def ada_grid_sample_bwd(gy, theta, gx, c):
+    B, Ho, Wo, Cp = gy.shape
+    _, Hs, Ws, _ = gx.shape
+    if gx.dtype != torch.float32:
+        raise RuntimeError("ada_grid_sample_bwd accumulates in fp32")
+    check(lib().o2m_ada_grid_sample_bwd(ptr(gy), ptr(theta), ptr(gx), B, Hs, Ws, Ho, Wo, c, Cp,
+                                        dtype_code(gy.dtype), _stream(gy)), "o2m_ada_grid_sample_bwd")
+
+
+def reflect_fold(gpad, gx, pad_top, pad_left):
+    B, Hp, Wp, Cp = gpad.shape
+    _, Hh, Ww, _ = gx.shape
+    check(lib().o2m_reflect_fold(ptr(gpad), ptr(gx), B, Hh, Ww, Hp, Wp, pad_top, pad_left, Cp,
+                                 dtype_code(gpad.dtype), dtype_code(gx.dtype), _stream(gx)), "o2m_reflect_fold")
+
+
+def ada_colour(x, m, y, c):
+    B, Hh, Ww, Cp = x.shape
+    check(lib().o2m_ada_colour(ptr(x), ptr(m), ptr(y), B, Hh * Ww, c, Cp, dtype_code(x.dtype), _stream(x)),
+          "o2m_ada_colour")
 
 
 def gather_images(pool, index, flip, out):

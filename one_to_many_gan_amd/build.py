@@ -14,7 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libo2m_hip.so")
-SOURCES = ["conv_igemm.hip", "conv_wgrad.hip", "pointwise.hip", "style.hip"]
+SOURCES = ["conv_igemm.hip", "conv_wgrad.hip", "pointwise.hip", "style.hip", "ada.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
          "-Wno-unused-value"]
 

@@ -636,7 +636,7 @@ inline unsigned grid_for(long n, int per_block = NT) {
 
 extern "C" {
 
-int o2m_abi_version(void) { return 9; }
+int o2m_abi_version(void) { return 10; }
 
 int o2m_modulate_weights(const float* w32, const float* s, void* out, int32_t B, int32_t Co,
                          int32_t KK, int32_t Ci, int32_t dtype, void* stream) {
@@ -774,6 +774,9 @@ int o2m_resample2d(const void* x, void* y, const int32_t* sy, const float* wy, c
     O2M_RESAMPLE_2X2(4, 4, 3, 3) O2M_RESAMPLE_2X2(4, 4, 2, 3) O2M_RESAMPLE_2X2(4, 4, 3, 2)
     // one axis at a time (the transposed upsample runs as a vertical and a horizontal pass)
     O2M_RESAMPLE_2X2(6, 1, 2, 1) O2M_RESAMPLE_2X2(1, 6, 1, 2)
+    // the 12-tap low-pass filters of the augmentation pipe (ada.py) and their transposes
+    O2M_RESAMPLE_2X2(12, 1, 2, 1) O2M_RESAMPLE_2X2(1, 12, 1, 2) O2M_RESAMPLE_2X2(6, 1, 1, 1)
+    O2M_RESAMPLE_2X2(1, 6, 1, 1)
 #undef O2M_RESAMPLE_2X2
   }
   if (Ty != Tx) return O2M_ERR_UNSUPPORTED;

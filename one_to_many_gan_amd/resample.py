@@ -119,6 +119,35 @@ def identity_taps(n: int, device):
     return hit
 
 
+def fit_taps(s, w, t, T, n_src):
+    """Widen a banded operator's rows from t to T taps, keeping every tap inside the source."""
+    if t == T:
+        return s, w
+    s2 = np.minimum(s, max(n_src - T, 0)).astype(np.int32)
+    w2 = np.zeros((w.shape[0], T), dtype=np.float32)
+    for r in range(w.shape[0]):
+        w2[r, s[r] - s2[r]: s[r] - s2[r] + t] = w[r]
+    return s2, w2
+
+
+def taps_from_matrices(a_h: np.ndarray, a_w: np.ndarray, device):
+    """The tuple ``taps`` returns, for two arbitrary banded operators [out][in] (vertical, horizontal)."""
+    sy, wy, ty = banded(np.ascontiguousarray(a_h))
+    sx, wx, tx = banded(np.ascontiguousarray(a_w))
+    T = max(ty, tx)
+    sy, wy = fit_taps(sy, wy, ty, T, a_h.shape[1])
+    sx, wx = fit_taps(sx, wx, tx, T, a_w.shape[1])
+    return (torch.from_numpy(sy).to(device), torch.from_numpy(np.ascontiguousarray(wy)).to(device),
+            torch.from_numpy(sx).to(device), torch.from_numpy(np.ascontiguousarray(wx)).to(device),
+            Taps(T, _span(sy), _span(sx)), wy.shape[0], wx.shape[0])
+
+
+def taps_1d(a: np.ndarray, device):
+    """(start, weights, T, span) of one banded operator [out][in] on the device."""
+    s, w, t = banded(np.ascontiguousarray(a))
+    return torch.from_numpy(s).to(device), torch.from_numpy(np.ascontiguousarray(w)).to(device), t, _span(s)
+
+
 def taps(kind: str, n_h: int, n_w: int, transposed: bool, device):
     """Device-resident taps for both axes, padded to a common T."""
     key = (kind, n_h, n_w, transposed, str(device))

@@ -64,7 +64,7 @@ def build(config, device):
 def run(config, device, steps, shoeprint_iter, shoemark_iter, resume=None, log=print):
     nets, opts = build(config, device)
     image_buffer = ImageBuffer(config["training"]["image_buffer_size"])
-    ada = o2m.IdentityADA().to(device)
+    ada = o2m.AdaptiveDiscriminatorAugmentation(**o2m.REFERENCE_ADA_SWITCHES).to(device)  # train.py:175-188
     ada_p = ADAp(ada_e=config["ada"]["ada_overfitting_measurement_n_images"],
                  ada_adjustment_size=config["ada"]["ada_adjustment_size"],
                  batch_size=config["training"]["batch_size"],
@@ -79,7 +79,7 @@ def run(config, device, steps, shoeprint_iter, shoemark_iter, resume=None, log=p
     t0 = time.perf_counter()
     for step in range(first, steps):
         p = ada_p()
-        ada.set_p(0.0 if p == 0 else p)  # raises for p > 0: the ADA transforms are not built
+        ada.set_p(p)
         logger.log_ada_ps.append(p)
         d_loss, (real_acc, fake_acc) = discriminator_step(
             config, device, nets["D"], nets["G"], nets["M"], opts["D"], shoeprint_iter, shoemark_iter,
