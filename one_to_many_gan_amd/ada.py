@@ -78,24 +78,46 @@ def _reflect(i, n):
     return np.where(i >= n, 2 * (n - 1) - i, i)
 
 
-def _pad_up_operator(n, m0, m1):
-    """[2L x n], L = n + m0 + m1: reflection padding, zero insertion, 12-tap convolution (gain 2)."""
+def _pad_up_coo(n, m0, m1):
+    """Reflection padding (m0, m1) + zero insertion + 12-tap convolution (gain 2) as COO triplets
+    of the [2L x n] operator, L = n + m0 + m1.  Output o meets the filter taps of its own parity:
+    k = (o & 1) + 2j, padded sample i = (o + k - 6) / 2."""
     L = n + m0 + m1
     f = SYM6 / SYM6.sum()
     ff = (2.0 * f)[::-1]
-    a = np.zeros((2 * L, n))
-    o = np.arange(2 * L)
-    for k in range(12):
-        z = o + k - 6  # position in the zero-inserted signal
-        ok = (z >= 0) & (z < 2 * L) & (z % 2 == 0)
-        src = _reflect(z[ok] // 2 - m0, n)
-        np.add.at(a, (o[ok], src), ff[k])
+    o = np.repeat(np.arange(2 * L), 6)
+    k = (o & 1) + 2 * np.tile(np.arange(6), 2 * L)
+    i = (o + k - 6) // 2
+    ok = (i >= 0) & (i < L)
+    return o[ok], _reflect(i[ok] - m0, n), ff[k[ok]], 2 * L, n
+
+
+def _up_t_coo(L):
+    """Adjoint of the 2x upsampling on the padded grid: [L x 2L], row i gathers outputs
+    o = 2i + 6 - k with weight ff[k]."""
+    f = SYM6 / SYM6.sum()
+    ff = (2.0 * f)[::-1]
+    i = np.repeat(np.arange(L), 12)
+    k = np.tile(np.arange(12), L)
+    o = 2 * i + 6 - k
+    ok = (o >= 0) & (o < 2 * L)
+    return i[ok], o[ok], ff[k[ok]], L, 2 * L
+
+
+def _dense(op):
+    rows, cols, vals, n_rows, n_cols = op
+    a = np.zeros((n_rows, n_cols))
+    np.add.at(a, (rows, cols), vals)
     return a
 
 
+def _pad_up_operator(n, m0, m1):
+    """Dense [2L x n] form of _pad_up_coo (tests, documentation)."""
+    return _dense(_pad_up_coo(n, m0, m1))
+
+
 def _up_operator(L):
-    """[2L x L]: the same without the padding (its transpose is the adjoint on the padded grid)."""
-    return _pad_up_operator(L, 0, 0)
+    return _dense(_pad_up_coo(L, 0, 0))
 
 
 def _down_operator(n):
@@ -302,11 +324,11 @@ class AdaptiveDiscriminatorAugmentation(nn.Module):
         g = _scale(b, 2 / ws, 2 / hs) @ g @ _scale(b, wo / 2, ho / 2)
         plan = _Plan()
         plan.theta = torch.from_numpy(np.ascontiguousarray(g[:, :2, :].reshape(b, 6)).astype(np.float32)).to(device)
-        plan.padup = R.taps_from_matrices(_pad_up_operator(height, my0, my1), _pad_up_operator(width, mx0, mx1), device)
+        plan.padup = R.taps_from_coo(_pad_up_coo(height, my0, my1), _pad_up_coo(width, mx0, mx1), device)
         if int(plan.padup[4]) > 8:
             raise RuntimeError("padding + upsampling operator wider than 8 taps")
-        plan.up_yt = R.taps_1d(_up_operator(ly).T, device)
-        plan.up_xt = R.taps_1d(_up_operator(lx).T, device)
+        plan.up_yt = R.taps_1d_coo(_up_t_coo(ly), device)
+        plan.up_xt = R.taps_1d_coo(_up_t_coo(lx), device)
         plan.down_y, plan.down_x = _down_taps(height, device), _down_taps(width, device)
         plan.h, plan.w, plan.ho, plan.wo = height, width, ho, wo
         plan.mx0, plan.my0, plan.channels = mx0, my0, channels

@@ -130,6 +130,41 @@ def fit_taps(s, w, t, T, n_src):
     return s2, w2
 
 
+def coo_width(rows, cols, n_rows):
+    """Band width (max over rows of last - first + 1) of an operator given as COO triplets."""
+    lo = np.full(n_rows, np.iinfo(np.int64).max, dtype=np.int64)
+    hi = np.full(n_rows, -1, dtype=np.int64)
+    np.minimum.at(lo, rows, cols)
+    np.maximum.at(hi, rows, cols)
+    used = hi >= 0
+    return (int((hi[used] - lo[used]).max()) + 1 if used.any() else 1), np.where(used, lo, 0)
+
+
+def banded_coo(rows, cols, vals, n_rows, n_cols, width=None):
+    """COO triplets (duplicates add) -> (start int32 [rows], weights fp32 [rows][T], T), vectorised:
+    the per-call operators of the augmentation pipe have ~1000 rows."""
+    w0, first = coo_width(rows, cols, n_rows)
+    T = min(max(w0, width or 1), n_cols)
+    start = np.minimum(first, n_cols - T)
+    w = np.zeros((n_rows, T), dtype=np.float64)
+    np.add.at(w, (rows, cols - start[rows]), vals)
+    return start.astype(np.int32), w.astype(np.float32), T
+
+
+def taps_from_coo(op_h, op_w, device):
+    """``taps`` tuple for two operators given as (rows, cols, vals, n_rows, n_cols)."""
+    T = max(coo_width(op_h[0], op_h[1], op_h[3])[0], coo_width(op_w[0], op_w[1], op_w[3])[0])
+    sy, wy, _ = banded_coo(*op_h, width=T)
+    sx, wx, _ = banded_coo(*op_w, width=T)
+    return (torch.from_numpy(sy).to(device), torch.from_numpy(wy).to(device), torch.from_numpy(sx).to(device),
+            torch.from_numpy(wx).to(device), Taps(T, _span(sy), _span(sx)), wy.shape[0], wx.shape[0])
+
+
+def taps_1d_coo(op, device):
+    s, w, t = banded_coo(*op)
+    return torch.from_numpy(s).to(device), torch.from_numpy(w).to(device), t, _span(s)
+
+
 def taps_from_matrices(a_h: np.ndarray, a_w: np.ndarray, device):
     """The tuple ``taps`` returns, for two arbitrary banded operators [out][in] (vertical, horizontal)."""
     sy, wy, ty = banded(np.ascontiguousarray(a_h))
