@@ -250,8 +250,9 @@ int o2m_gather_images(const uint8_t* pool, const int32_t* index, const uint8_t* 
  * o2m_ada_grid_sample: F.affine_grid(theta, align_corners=False) + F.grid_sample(bilinear,
  *   zeros padding, align_corners=False) of x [B][Hs][Ws][Cp] into y [B][Ho][Wo][Cp];
  *   theta fp32 [B][2][3] in normalised coordinates.
- * o2m_ada_grid_sample_bwd: its adjoint; gx fp32 [B][Hs][Ws][Cp], ZEROED by the caller, receives
- *   atomic adds for the C real channels.
+ * o2m_ada_grid_sample_bwd: its adjoint, as a gather (one thread per source pixel enumerates the
+ *   outputs whose bilinear footprint covers it; no atomics); gx [B][Hs][Ws][Cp] in `dtype`, fully
+ *   written (zeros outside the sampled region).
  * o2m_reflect_fold: adjoint of F.pad(mode="reflect") with margins (pad_left, Wp-W-pad_left,
  *   pad_top, Hp-H-pad_top), each smaller than the image; gpad [B][Hp][Wp][Cp] (in_dtype) ->
  *   gx [B][H][W][Cp] (out_dtype).
@@ -262,9 +263,9 @@ int o2m_gather_images(const uint8_t* pool, const int32_t* index, const uint8_t* 
  */
 int o2m_ada_grid_sample(const void* x, const float* theta, void* y, int32_t B, int32_t Hs,
                         int32_t Ws, int32_t Ho, int32_t Wo, int32_t Cp, int32_t dtype, void* stream);
-int o2m_ada_grid_sample_bwd(const void* gy, const float* theta, float* gx, int32_t B, int32_t Hs,
-                            int32_t Ws, int32_t Ho, int32_t Wo, int32_t C, int32_t Cp,
-                            int32_t dtype, void* stream);
+int o2m_ada_grid_sample_bwd(const void* gy, const float* theta, void* gx, int32_t B, int32_t Hs,
+                            int32_t Ws, int32_t Ho, int32_t Wo, int32_t Cp, int32_t dtype,
+                            void* stream);
 int o2m_reflect_fold(const void* gpad, void* gx, int32_t B, int32_t H, int32_t W, int32_t Hp,
                      int32_t Wp, int32_t pad_top, int32_t pad_left, int32_t Cp, int32_t in_dtype,
                      int32_t out_dtype, void* stream);

@@ -20,7 +20,7 @@ BF16, F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 PAD_ZERO, PAD_REFLECT = 0, 1
 RED_L1, RED_SQ, RED_MOM = 0, 1, 2
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -60,7 +60,7 @@ SIGNATURES = {
     "o2m_resample2d": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                               _i32, _i32, _i32, _i32, _vp]),
     "o2m_ada_grid_sample": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
-    "o2m_ada_grid_sample_bwd": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "o2m_ada_grid_sample_bwd": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "o2m_reflect_fold": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "o2m_ada_colour": (_i32, [_vp, _vp, _vp, _i32, C.c_int64, _i32, _i32, _i32, _vp]),
     "o2m_gather_images": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
@@ -291,13 +291,13 @@ def ada_grid_sample(x, theta, y):
                                     _stream(x)), "o2m_ada_grid_sample")
 
 
-def ada_grid_sample_bwd(gy, theta, gx, c):
+def ada_grid_sample_bwd(gy, theta, gx):
     B, Ho, Wo, Cp = gy.shape
     _, Hs, Ws, _ = gx.shape
-    if gx.dtype != torch.float32:
-        raise RuntimeError("ada_grid_sample_bwd accumulates in fp32")
-    check(lib().o2m_ada_grid_sample_bwd(ptr(gy), ptr(theta), ptr(gx), B, Hs, Ws, Ho, Wo, c, Cp,
-                                        dtype_code(gy.dtype), _stream(gy)), "o2m_ada_grid_sample_bwd")
+    if gx.dtype != gy.dtype:
+        raise RuntimeError("ada_grid_sample_bwd: gx and gy share one dtype")
+    check(lib().o2m_ada_grid_sample_bwd(ptr(gy), ptr(theta), ptr(gx), B, Hs, Ws, Ho, Wo, Cp, dtype_code(gy.dtype),
+                                        _stream(gy)), "o2m_ada_grid_sample_bwd")
 
 
 def reflect_fold(gpad, gx, pad_top, pad_left):

@@ -15,8 +15,8 @@ MI355X design
   through o2m_resample2d with operators composed on the host (reflection maps a contiguous window
   onto a contiguous window, so padding folds into the upsampling operator); the 12-tap stages run
   as a vertical and a horizontal 1-D pass.  The resampling in the middle is o2m_ada_grid_sample.
-* Backward = the adjoints in reverse: transposed banded operators, the atomic scatter
-  o2m_ada_grid_sample_bwd into an fp32 buffer, o2m_reflect_fold for the padding.
+* Backward = the adjoints in reverse: transposed banded operators, o2m_ada_grid_sample_bwd (a
+  gather: each source pixel enumerates the few outputs that sample it), o2m_reflect_fold.
 * Colour = one per-pixel 3x4 affine (o2m_ada_colour); its adjoint is the transposed matrix.
 """
 
@@ -134,20 +134,22 @@ class _Plan:
 
 
 def _pass(x, start, weights, t, span, axis):
-    """One 1-D banded pass along ``axis`` (1 = vertical, 2 = horizontal) of an NHWC buffer."""
+    """One 1-D banded pass along ``axis`` (1 = vertical, 2 = horizontal) of an NHWC buffer; span 0
+    selects the per-output kernel (arbitrary starts, 6..8 taps)."""
     B, Hh, Ww, Cn = x.shape
     n_out = weights.shape[0]
     # ``span`` is an upper bound on the step between tap starts; the instantiated 1-D kernels are
     # (12 taps, span 2) and (6 taps, span 1 or 2)
-    span = max(span, 2 if t == 12 else 1)
+    if span > 0:
+        span = max(span, 2 if t == 12 else 1)
     if axis == 1:
         ix, iw = R.identity_taps(Ww, x.device)
         y = torch.empty((B, n_out, Ww, Cn), dtype=x.dtype, device=x.device)
-        H.resample2d(x, y, start, weights, ix, iw, t, 1, span, 1)
+        H.resample2d(x, y, start, weights, ix, iw, t, 1, span, 1 if span else 0)
     else:
         iy, iw = R.identity_taps(Hh, x.device)
         y = torch.empty((B, Hh, n_out, Cn), dtype=x.dtype, device=x.device)
-        H.resample2d(x, y, iy, iw, start, weights, 1, t, 1, span)
+        H.resample2d(x, y, iy, iw, start, weights, 1, t, 1 if span else 0, span)
     return y
 
 
@@ -167,7 +169,10 @@ def _down_taps(n, device):
 class _GeometryFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, t, plan):
-        x1 = ops._apply_taps(t, plan.padup)  # [B][2Ly][2Lx][Cp]
+        # pad + upsample as a vertical and a horizontal 1-D pass (6..8 + 6..8 loads per output instead
+        # of T^2; the starts are not monotonic across the mirror, so the per-output kernel)
+        sy, wy, sx, wx, T, _, _ = plan.padup
+        x1 = _pass(_pass(t, sy, wy, int(T), 0, 1), sx, wx, int(T), 0, 2)  # [B][2Ly][2Lx][Cp]
         B = t.shape[0]
         x2 = torch.empty((B, plan.ho, plan.wo, t.shape[3]), dtype=t.dtype, device=t.device)
         H.ada_grid_sample(x1, plan.theta, x2)
@@ -182,9 +187,8 @@ class _GeometryFn(torch.autograd.Function):
         g = g.contiguous()
         (_, dyt), (_, dxt) = plan.down_y, plan.down_x
         g2 = _pass(_pass(g, *dxt, 2), *dyt, 1)  # [B][Ho][Wo][Cp]
-        g1 = torch.zeros(ctx.src_shape, dtype=torch.float32, device=g.device)
-        H.ada_grid_sample_bwd(g2, plan.theta, g1, plan.channels)
-        g1 = g1.to(g.dtype)
+        g1 = torch.empty(ctx.src_shape, dtype=g.dtype, device=g.device)
+        H.ada_grid_sample_bwd(g2, plan.theta, g1)
         gp = _pass(_pass(g1, *plan.up_yt, 1), *plan.up_xt, 2)  # padded grid [B][Ly][Lx][Cp]
         gx = torch.empty((g.shape[0], plan.h, plan.w, g.shape[3]), dtype=g.dtype, device=g.device)
         H.reflect_fold(gp, gx, plan.my0, plan.mx0)
@@ -324,9 +328,9 @@ class AdaptiveDiscriminatorAugmentation(nn.Module):
         g = _scale(b, 2 / ws, 2 / hs) @ g @ _scale(b, wo / 2, ho / 2)
         plan = _Plan()
         plan.theta = torch.from_numpy(np.ascontiguousarray(g[:, :2, :].reshape(b, 6)).astype(np.float32)).to(device)
-        plan.padup = R.taps_from_coo(_pad_up_coo(height, my0, my1), _pad_up_coo(width, mx0, mx1), device)
-        if int(plan.padup[4]) > 8:
-            raise RuntimeError("padding + upsampling operator wider than 8 taps")
+        plan.padup = R.taps_from_coo(_pad_up_coo(height, my0, my1), _pad_up_coo(width, mx0, mx1), device, min_width=6)
+        if not 6 <= int(plan.padup[4]) <= 8:
+            raise RuntimeError("padding + upsampling operator outside the instantiated 6..8 taps")
         plan.up_yt = R.taps_1d_coo(_up_t_coo(ly), device)
         plan.up_xt = R.taps_1d_coo(_up_t_coo(lx), device)
         plan.down_y, plan.down_x = _down_taps(height, device), _down_taps(width, device)

@@ -301,7 +301,7 @@ __global__ __launch_bounds__(NT) void in_apply_kernel(const T* __restrict__ x, c
 // are all loaded up front (independent loads in flight) instead of a dependent
 // weight -> index -> data chain per tap.  Source indices are clamped (taps whose weight is
 // zero may point past the edge).
-template <typename T, int TN>
+template <typename T, int TY, int TX>
 __global__ __launch_bounds__(NT) void resample_kernel(const T* x, T* y, const int* sy,
                                                       const float* wy, const int* sx,
                                                       const float* wx, int H, int W, int Ho,
@@ -314,21 +314,23 @@ __global__ __launch_bounds__(NT) void resample_kernel(const T* x, T* y, const in
     const int oy = (int)(r % Ho);
     const int b = (int)(r / Ho);
     const int y0 = sy[oy], x0 = sx[ox];
-    float a[TN], c[TN];
+    float a[TY], c[TX];
 #pragma unroll
-    for (int t = 0; t < TN; ++t) { a[t] = wy[oy * TN + t]; c[t] = wx[ox * TN + t]; }
+    for (int t = 0; t < TY; ++t) a[t] = wy[oy * TY + t];
+#pragma unroll
+    for (int t = 0; t < TX; ++t) c[t] = wx[ox * TX + t];
     const T* base = x + ((size_t)b * H * W) * C + cv * 8;
     float acc[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = 0.f;
 #pragma unroll
-    for (int ty = 0; ty < TN; ++ty) {
+    for (int ty = 0; ty < TY; ++ty) {
       const int iy = min(y0 + ty, H - 1);
       float row[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) row[i] = 0.f;
 #pragma unroll
-      for (int tx = 0; tx < TN; ++tx) {
+      for (int tx = 0; tx < TX; ++tx) {
         const int ix = min(x0 + tx, W - 1);
         float t[8];
         load8(base + ((size_t)iy * W + ix) * C, t);
@@ -636,7 +638,7 @@ inline unsigned grid_for(long n, int per_block = NT) {
 
 extern "C" {
 
-int o2m_abi_version(void) { return 10; }
+int o2m_abi_version(void) { return 11; }
 
 int o2m_modulate_weights(const float* w32, const float* s, void* out, int32_t B, int32_t Co,
                          int32_t KK, int32_t Ci, int32_t dtype, void* stream) {
@@ -779,21 +781,20 @@ int o2m_resample2d(const void* x, void* y, const int32_t* sy, const float* wy, c
     O2M_RESAMPLE_2X2(1, 6, 1, 1)
 #undef O2M_RESAMPLE_2X2
   }
-  if (Ty != Tx) return O2M_ERR_UNSUPPORTED;
-  const int T_ = Ty;
-#define O2M_RESAMPLE_CASE(TN)                                                                   \
-  case TN:                                                                                       \
-    DISPATCH_T(dtype, hipLaunchKernelGGL((resample_kernel<T, TN>), dim3(grid_for(nvec)), dim3(NT), 0, s, \
+#define O2M_RESAMPLE_CASE(TY, TX)                                                                \
+  if (Ty == TY && Tx == TX) {                                                                    \
+    DISPATCH_T(dtype, hipLaunchKernelGGL((resample_kernel<T, TY, TX>), dim3(grid_for(nvec)), dim3(NT), 0, s, \
                                          (const T*)x, (T*)y, sy, wy, sx, wx, H, W, Ho, Wo, C, nvec)); \
-    break;
-  switch (T_) {
-    O2M_RESAMPLE_CASE(1) O2M_RESAMPLE_CASE(2) O2M_RESAMPLE_CASE(3) O2M_RESAMPLE_CASE(4)
-    O2M_RESAMPLE_CASE(5) O2M_RESAMPLE_CASE(6) O2M_RESAMPLE_CASE(7) O2M_RESAMPLE_CASE(8)
-    default: return O2M_ERR_UNSUPPORTED;
+    O2M_LAUNCH_CHECK();                                                                          \
+    return 0;                                                                                    \
   }
+  O2M_RESAMPLE_CASE(1, 1) O2M_RESAMPLE_CASE(2, 2) O2M_RESAMPLE_CASE(3, 3) O2M_RESAMPLE_CASE(4, 4)
+  O2M_RESAMPLE_CASE(5, 5) O2M_RESAMPLE_CASE(6, 6) O2M_RESAMPLE_CASE(7, 7) O2M_RESAMPLE_CASE(8, 8)
+  // 1-D passes with arbitrary (non-monotonic) starts: reflection padding folded into an upsampling
+  O2M_RESAMPLE_CASE(6, 1) O2M_RESAMPLE_CASE(1, 6) O2M_RESAMPLE_CASE(7, 1) O2M_RESAMPLE_CASE(1, 7)
+  O2M_RESAMPLE_CASE(8, 1) O2M_RESAMPLE_CASE(1, 8)
+  return O2M_ERR_UNSUPPORTED;
 #undef O2M_RESAMPLE_CASE
-  O2M_LAUNCH_CHECK();
-  return 0;
 }
 
 int o2m_gather_images(const uint8_t* pool, const int32_t* index, const uint8_t* flip, void* out,

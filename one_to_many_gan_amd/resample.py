@@ -151,9 +151,9 @@ def banded_coo(rows, cols, vals, n_rows, n_cols, width=None):
     return start.astype(np.int32), w.astype(np.float32), T
 
 
-def taps_from_coo(op_h, op_w, device):
+def taps_from_coo(op_h, op_w, device, min_width=1):
     """``taps`` tuple for two operators given as (rows, cols, vals, n_rows, n_cols)."""
-    T = max(coo_width(op_h[0], op_h[1], op_h[3])[0], coo_width(op_w[0], op_w[1], op_w[3])[0])
+    T = max(coo_width(op_h[0], op_h[1], op_h[3])[0], coo_width(op_w[0], op_w[1], op_w[3])[0], min_width)
     sy, wy, _ = banded_coo(*op_h, width=T)
     sx, wx, _ = banded_coo(*op_w, width=T)
     return (torch.from_numpy(sy).to(device), torch.from_numpy(wy).to(device), torch.from_numpy(sx).to(device),

@@ -132,8 +132,8 @@ def test_ada_kernels_against_torch():
     assert float((out[..., :C].double().cpu().permute(0, 3, 1, 2) - ref.detach()).abs().max()) < 1e-4
     gy = torch.zeros(B, 26, 34, Cp, device="cuda")
     gy[..., :C] = torch.randn(B, 26, 34, C, device="cuda")
-    gsrc = torch.zeros(B, 30, 44, Cp, device="cuda")
-    H.ada_grid_sample_bwd(gy, theta.reshape(B, 6).cuda(), gsrc, C)
+    gsrc = torch.full((B, 30, 44, Cp), 9.0, device="cuda")  # fully overwritten
+    H.ada_grid_sample_bwd(gy, theta.reshape(B, 6).cuda(), gsrc)
     (ref * gy[..., :C].double().cpu().permute(0, 3, 1, 2)).sum().backward()
     assert float((gsrc[..., :C].double().cpu().permute(0, 3, 1, 2) - s64.grad).abs().max()) < 1e-3
     assert float(gsrc[..., C:].abs().max()) == 0.0
