@@ -226,13 +226,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
     }
   };
 
-  // DMA mode: element offsets of this lane's filter rows (or -1)
-  int dwoff[FB];
+  // DMA mode: byte offsets of this lane's filter rows (or the out-of-range mark)
+  unsigned dwoff[FB];
 #pragma unroll
   for (int j = 0; j < FB; ++j) {
     const int q = (dwave % LW) * FB + j;
     const int n = n0 + dma_row(q);
-    dwoff[j] = (DMA && n < Co) ? n * K + dma_chk(q) * 8 : -1;
+    dwoff[j] = (DMA && n < Co) ? (unsigned)(n * K + dma_chk(q) * 8) * 2u : OOB_OFF;
   }
   const unsigned short* Xg = static_cast<const unsigned short*>(d.x);
   const unsigned short* Wg = static_cast<const unsigned short*>(d.w) + (size_t)b_first * d.w_batch_stride;
@@ -247,19 +247,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
     if (tap != cur_tap) { set_tap(tap); cur_tap = tap; }
     char* a_dst = smem + stage * STAGE_BYTES + dwave * FA * 1024;
     char* b_dst = smem + stage * STAGE_BYTES + A_BYTES + dwave * FB * 1024;
+    // buffer_load_dwordx4 ... lds: descriptor + this lane's byte offset (computed once per tap) +
+    // the stage's channel offset in an SGPR.  No 64-bit pointer arithmetic and no select per fill,
+    // and an out-of-range offset (padding tap, row outside the problem) zero-fills its LDS slot
+    // (checked on hardware: tools/probe_buffer_lds.py), so the zero page is not needed here.
 #pragma unroll
-    for (int j = 0; j < FA; ++j) {
-      const void* src = aoff[j] != OOB_OFF
-                            ? static_cast<const void*>(reinterpret_cast<const char*>(Xg) + aoff[j] + (unsigned)cbase * 2)
-                            : static_cast<const void*>(o2m_zero16);
-      __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(a_dst + j * 1024), 16, 0, 0);
-    }
+    for (int j = 0; j < FA; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void*)(a_dst + j * 1024), 16, (int)aoff[j], cbase * 2, 0, 0);
 #pragma unroll
-    for (int j = 0; j < FB; ++j) {
-      const void* src = dwoff[j] >= 0 ? static_cast<const void*>(Wg + dwoff[j] + k0)
-                                      : static_cast<const void*>(o2m_zero16);
-      __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(b_dst + j * 1024), 16, 0, 0);
-    }
+    for (int j = 0; j < FB; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void*)(b_dst + j * 1024), 16, (int)dwoff[j], k0 * 2, 0, 0);
   };
 
   auto load_tiles = [&](int kt) {
