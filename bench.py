@@ -88,7 +88,11 @@ class Trainer:
 
     def step(self):
         """The loop body of train.py:204-251."""
-        self.ada.set_p(self.ada_p())
+        # The benchmark workload holds the augmentation at p = 0 (SURVEY.md section 8d; the CPU oracle
+        # has no transforms): the ADAp controller still runs inside discriminator_step, its output
+        # is read like train.py:206 does, but not applied.
+        self.ada_p()
+        self.ada.set_p(0.0)
         d_out = self.ns.discriminator_step(self.cfg, self.device, self.D, self.G, self.M, self.oD,
                                            self.prints, self.marks, self.buffer, self.ada, self.ada_p)
         kw = {"kl_moment_hook": self.kl_hook} if self.kl_hook is not None else {}
