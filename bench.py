@@ -156,7 +156,7 @@ def kernel_profile(trainer, precision):
     # with the gfx950 correction), committed under profiles/: PMC cannot be read from inside the run
     traffic = None
     try:
-        rec = json.load(open(os.path.join(ROOT, "profiles", "r01_d_pmc_traffic.json")))
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r01_k_pmc_igemm_final.json")))
         if rec.get("kernel") == name:
             traffic = rec["fabric_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
