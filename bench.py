@@ -84,6 +84,7 @@ class Trainer:
         self.ada_p = ns.ADAp(cfg["ada"]["ada_overfitting_measurement_n_images"], cfg["ada"]["ada_adjustment_size"],
                              b, cfg["ada"]["discriminator_real_acc_target"])
         self.kl_hook = None
+        self.fixed_ada_p = 0.0  # --ada-p: a fixed augmentation probability (not part of the headline workload)
         torch.manual_seed(t["random_seed"] + 1 + seed_offset)  # z / theta / h streams differ per rank
 
     def step(self):
@@ -92,7 +93,7 @@ class Trainer:
         # has no transforms): the ADAp controller still runs inside discriminator_step, its output
         # is read like train.py:206 does, but not applied.
         self.ada_p()
-        self.ada.set_p(0.0)
+        self.ada.set_p(self.fixed_ada_p)
         d_out = self.ns.discriminator_step(self.cfg, self.device, self.D, self.G, self.M, self.oD,
                                            self.prints, self.marks, self.buffer, self.ada, self.ada_p)
         kw = {"kl_moment_hook": self.kl_hook} if self.kl_hook is not None else {}
@@ -101,7 +102,7 @@ class Trainer:
         return d_out, g_out
 
 
-def product_namespace(precision):
+def product_namespace(precision, ada_p=0.0):
     from types import SimpleNamespace
 
     import one_to_many_gan_amd as pk
@@ -113,7 +114,9 @@ def product_namespace(precision):
     return SimpleNamespace(Discriminator=pb.Discriminator, Generator=pb.Generator,
                            MappingNetwork=pb.MappingNetwork, StyleExtractor=pb.StyleExtractor,
                            make_adam=pk.make_adam, ImageBuffer=pt.ImageBuffer, ADAp=pl.ADAp,
-                           make_ada=pk.IdentityADA, discriminator_step=pt.discriminator_step,
+                           make_ada=(pk.IdentityADA if ada_p == 0 else
+                                     (lambda: pk.AdaptiveDiscriminatorAugmentation(**pk.REFERENCE_ADA_SWITCHES))),
+                           discriminator_step=pt.discriminator_step,
                            generator_step=pt.generator_step)
 
 
@@ -195,6 +198,9 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--channels", type=int, default=3)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--ada-p", type=float, default=0.0,
+                    help="hold the augmentation at this probability instead of 0 (extra measurement: the "
+                         "headline workload and the CPU baseline are defined at p = 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--dump-params", default=None, help="write a checksum of every rank's weights (tests)")
@@ -219,7 +225,8 @@ def main():
             dist.init_process_group(backend)
 
     cfg = make_config(args.size, args.channels, args.batch)
-    trainer = Trainer(product_namespace(args.precision), cfg, device, seed_offset=rank)
+    trainer = Trainer(product_namespace(args.precision, args.ada_p), cfg, device, seed_offset=rank)
+    trainer.fixed_ada_p = args.ada_p
     if world > 1:
         from one_to_many_gan_amd import dist as o2m_dist
 
@@ -259,7 +266,7 @@ def main():
         "dtype": args.precision, "data": "synthetic",
         "config": {"workload": f"{args.size}x{args.size}x{args.channels} D+G step (discriminator_step + "
                                f"generator_step), batch {args.batch}/GPU, stock config.toml hyper-parameters, "
-                               "ADA at p=0", "global_batch": args.batch * world,
+                               f"ADA at p={args.ada_p:g}", "global_batch": args.batch * world,
                    "parallelism": f"dp{world}", "last_losses": {"d": last[0][0], "g": last[1][0]}},
     }
     if flop:
