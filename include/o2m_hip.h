@@ -111,6 +111,8 @@ int o2m_modulate_weights(const float* w32, const float* s, void* out, int32_t B,
  *        o2m_fold_scale_dot, Q [Cop][Cip] -> e [B][Cop], gs [B][Cip] (workspaces),
  *        gw [B][WD], gWs [Ci][WD], gbs [Ci]; gq [Cop][Cip] += dL/dQ (accumulated: the layer may be
  *        used several times in one backward).   d NULL: no demodulation.
+  * accumulate != 0: gWs / gbs are ADDED to (one writer per element: pass the parameters' .grad
+ *   buffers and the five uses of a decoder layer per step need no autograd additions).
  */
 int o2m_style_fwd(const float* w, const float* Ws, const float* bs, const float* Qt, float* s,
                   float* d, int32_t B, int32_t WD, int32_t Ci, int32_t Cip, int32_t Cop, float cs,
@@ -118,7 +120,7 @@ int o2m_style_fwd(const float* w, const float* Ws, const float* bs, const float*
 int o2m_style_bwd(const float* sums, const float* bias, const float* dots, const float* s,
                   const float* d, const float* Q, const float* w, const float* Ws, float* e,
                   float* gs, float* gw, float* gWs, float* gbs, float* gq, int32_t B, int32_t WD,
-                  int32_t Ci, int32_t Cip, int32_t Cop, float cs, void* stream);
+                  int32_t Ci, int32_t Cip, int32_t Cop, float cs, int32_t accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Weight gradient of the convolution above (the wgrad half of aten::convolution_backward

@@ -20,7 +20,7 @@ BF16, F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 PAD_ZERO, PAD_REFLECT = 0, 1
 RED_L1, RED_SQ, RED_MOM = 0, 1, 2
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -47,7 +47,7 @@ SIGNATURES = {
     "o2m_conv2d_wgrad": (_i32, [C.POINTER(WgradDesc), _vp]),
     "o2m_wgrad_finalize": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
     "o2m_style_fwd": (_i32, [_vp] * 6 + [_i32] * 5 + [_f32, _f32, _vp]),
-    "o2m_style_bwd": (_i32, [_vp] * 14 + [_i32] * 5 + [_f32, _vp]),
+    "o2m_style_bwd": (_i32, [_vp] * 14 + [_i32] * 5 + [_f32, _i32, _vp]),
     "o2m_act_bwd_reduce": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "o2m_prepare_weights": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, C.c_float,
                                    _i32, _vp]),
@@ -217,13 +217,13 @@ def style_fwd(w, ws, bs, qt, s, d, ci, cs, eps):
                               eps, _stream(s)), "o2m_style_fwd")
 
 
-def style_bwd(sums, bias, dots, s, d, q, w, ws, e, gs, gw, gws, gbs, gq, ci, cs):
+def style_bwd(sums, bias, dots, s, d, q, w, ws, e, gs, gw, gws, gbs, gq, ci, cs, accumulate=False):
     B, WD = w.shape
     cip = s.shape[1]
     cop = d.shape[1] if d is not None else 8
     check(lib().o2m_style_bwd(ptr(sums), ptr(bias), ptr(dots), ptr(s), ptr(d), ptr(q), ptr(w), ptr(ws),
                               ptr(e), ptr(gs), ptr(gw), ptr(gws), ptr(gbs), ptr(gq), B, WD, ci, cip, cop, cs,
-                              _stream(s)), "o2m_style_bwd")
+                              int(bool(accumulate)), _stream(s)), "o2m_style_bwd")
 
 
 def wgrad_finalize(acc, gq, w32, grad, co, ci, c):

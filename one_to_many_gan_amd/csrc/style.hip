@@ -109,7 +109,7 @@ __global__ __launch_bounds__(NT) void style_bwd_sample_kernel(
 __global__ __launch_bounds__(NT) void style_bwd_batch_kernel(const float* gs, const float* w, const float* e,
                                                              const float* s, float* gWs, float* gbs, float* gq,
                                                              int B, int WD, int Ci, int Cip, int Cop, float cs,
-                                                             int param_blocks) {
+                                                             int param_blocks, int accumulate) {
   if ((int)blockIdx.x < param_blocks) {
     const int i = blockIdx.x * NT + threadIdx.x;
     if (i >= Ci) return;
@@ -121,8 +121,14 @@ __global__ __launch_bounds__(NT) void style_bwd_batch_kernel(const float* gs, co
       sb += g;
       for (int j = 0; j < WD; ++j) acc[j] += g * w[(size_t)b * WD + j];
     }
-    gbs[i] = sb;
-    for (int j = 0; j < WD; ++j) gWs[(size_t)i * WD + j] = acc[j] * cs;
+    // one writer per element: accumulate = 1 adds into the caller's buffers (the parameters' .grad)
+    if (accumulate) {
+      gbs[i] += sb;
+      for (int j = 0; j < WD; ++j) gWs[(size_t)i * WD + j] += acc[j] * cs;
+    } else {
+      gbs[i] = sb;
+      for (int j = 0; j < WD; ++j) gWs[(size_t)i * WD + j] = acc[j] * cs;
+    }
     return;
   }
   if (!gq) return;
@@ -156,7 +162,7 @@ int o2m_style_fwd(const float* w, const float* Ws, const float* bs, const float*
 int o2m_style_bwd(const float* sums, const float* bias, const float* dots, const float* s, const float* d,
                   const float* Q, const float* w, const float* Ws, float* e, float* gs, float* gw,
                   float* gWs, float* gbs, float* gq, int32_t B, int32_t WD, int32_t Ci, int32_t Cip,
-                  int32_t Cop, float cs, void* stream) {
+                  int32_t Cop, float cs, int32_t accumulate, void* stream) {
   if (!dots || !s || !w || !Ws || !gs || !gw || !gWs || !gbs) return O2M_ERR_BAD_ARG;
   if (B <= 0 || WD <= 0 || WD > MAXWD || Ci <= 0 || Cip < Ci || Cop <= 0) return O2M_ERR_BAD_ARG;
   if (d && (!sums || !Q || !e || !gq)) return O2M_ERR_BAD_ARG;
@@ -168,7 +174,7 @@ int o2m_style_bwd(const float* sums, const float* bias, const float* dots, const
   O2M_LAUNCH_CHECK();
   const int pb = (Ci + NT - 1) / NT;
   hipLaunchKernelGGL(style_bwd_batch_kernel, dim3(pb + (d ? Cop : 0)), dim3(NT), 0, st, gs, w, e, s, gWs, gbs,
-                     d ? gq : nullptr, B, WD, Ci, Cip, Cop, cs, pb);
+                     d ? gq : nullptr, B, WD, Ci, Cip, Cop, cs, pb, accumulate);
   O2M_LAUNCH_CHECK();
   return 0;
 }

@@ -221,6 +221,10 @@ _DEFER_WGRAD = _os.environ.get("O2M_DEFER_WGRAD", "0") == "1"
 # stream, ordered by events, so they overlap the neighbouring convolution kernels.
 _SIDE_STREAM = _os.environ.get("O2M_SIDE_STREAM", "1") == "1"
 _SIDE: dict = {}
+# O2M_DIRECT_STYLE_GRADS=1: the style-gradient kernel adds the to_style gradients straight into the
+# parameters' .grad (no autograd additions for the five uses of a decoder layer per step).  Saves
+# ~100 tiny launches but measured no faster (56.4 vs 55.4 ms/step, same box), so it is off.
+_DIRECT_STYLE_GRADS = _os.environ.get("O2M_DIRECT_STYLE_GRADS", "0") == "1"
 
 
 # O2M_WGRAD_STREAM=1: the weight-gradient reductions are off the critical path of backward (only
@@ -360,6 +364,7 @@ class _ConvFn(torch.autograd.Function):
             H.conv2d_fwd(x, w_f, y, in_scale=s, out_scale=d, bias=bias_p, residual=residual,
                          pad=pad, pad_mode=pad_mode, act=act)
         ctx.prep, ctx.pad, ctx.pad_mode, ctx.act = prep, pad, pad_mode, act
+        ctx.ts_params = (ts_weight, ts_bias)
         ctx.has_bias, ctx.has_res = bias is not None, residual is not None
         ctx.save_for_backward(x, y, residual, s, d, weight, bias_p, wv, ws)
         return y
@@ -422,8 +427,18 @@ class _ConvFn(torch.autograd.Function):
             e = torch.empty((B, prep.cop), dtype=torch.float32, device=dev) if d is not None else None
             gs = torch.empty((B, cip), dtype=torch.float32, device=dev)
             g_ws = torch.empty((B, wd_), dtype=torch.float32, device=dev)
-            g_tw = torch.empty((prep.ci, wd_), dtype=torch.float32, device=dev)
-            g_tb = torch.empty((prep.ci,), dtype=torch.float32, device=dev)
+            # to_style gradients: a decoder layer is applied five times per generator step; when the
+            # parameters already own fp32 .grad buffers (FusedAdam's flat bucket) the kernel adds
+            # straight into them instead of autograd summing five temporaries per parameter
+            tsw, tsb = ctx.ts_params
+            direct = _DIRECT_STYLE_GRADS and all(
+                ctx.needs_input_grad[k] and p is not None and p.grad is not None and p.grad.dtype == torch.float32
+                and p.grad.is_contiguous() and p.grad.device == dev for k, p in ((4, tsw), (5, tsb)))
+            if direct:
+                g_tw, g_tb = tsw.grad, tsb.grad
+            else:
+                g_tw = torch.empty((prep.ci, wd_), dtype=torch.float32, device=dev)
+                g_tb = torch.empty((prep.ci,), dtype=torch.float32, device=dev)
             gq_tmp = None
             if d is not None and not need_w:  # dL/dQ is discarded when the filter wants no gradient
                 gq_tmp = torch.zeros((prep.cop, cip), dtype=torch.float32, device=dev)
@@ -463,13 +478,15 @@ class _ConvFn(torch.autograd.Function):
                 side.wait_event(ev_pre)
                 with torch.cuda.stream(side):
                     H.style_bwd(sums, bias_p, dots, s, d, q, wv, ws, e, gs, g_ws, g_tw, g_tb, gq, prep.ci,
-                                1.0 / math.sqrt(wd_))
+                                1.0 / math.sqrt(wd_), accumulate=direct)
                     ev_done = torch.cuda.Event()
                     ev_done.record(side)
                 main.wait_event(ev_done)
             else:
                 H.style_bwd(sums, bias_p, dots, s, d, q, wv, ws, e, gs, g_ws, g_tw, g_tb, gq, prep.ci,
-                            1.0 / math.sqrt(wd_))
+                            1.0 / math.sqrt(wd_), accumulate=direct)
+            if direct:
+                g_tw = g_tb = None  # already in .grad
         else:
             g_ws = g_tw = g_tb = None
         g_res = g if (ctx.has_res and need_res) else None
