@@ -143,3 +143,29 @@ def test_c_abi_rejects_bad_arguments():
     ws = torch.zeros(4, device="cuda")
     with pytest.raises(RuntimeError, match="10001"):  # tanh has no InstanceNorm backward here
         H.instnorm_bwd(y, y, torch.zeros(1, 8, 2, device="cuda"), ws, torch.zeros(1, 8, 2, device="cuda"), y, H.ACT_TANH)
+
+
+def test_c_abi_rejects_bad_arguments_of_the_widened_entry_points():
+    """o2m_gather_images / o2m_ada_* / o2m_reflect_fold / o2m_prepare_weights / o2m_resample2d refuse
+    malformed calls before launching anything."""
+    from one_to_many_gan_amd import _hip as H
+
+    dev = "cuda"
+    img = torch.zeros(2, 8, 8, 8, device=dev, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="uint8"):  # pool must be uint8
+        H.gather_images(torch.zeros(4, 8, 8, 3, device=dev), torch.zeros(2, dtype=torch.int32, device=dev),
+                        torch.zeros(2, dtype=torch.uint8, device=dev), img)
+    with pytest.raises(RuntimeError, match="10001"):  # colour transforms: 1 or 3 real channels
+        H.ada_colour(img, torch.zeros(2, 3, 4, device=dev), torch.empty_like(img), 2)
+    with pytest.raises(RuntimeError, match="10001"):  # a reflection margin must be smaller than the image
+        H.reflect_fold(torch.zeros(2, 8 + 8, 8, 8, device=dev, dtype=torch.bfloat16), img, 8, 0)
+    with pytest.raises(RuntimeError, match="dtype"):  # gather adjoint writes the gradient's dtype
+        H.ada_grid_sample_bwd(img, torch.zeros(2, 6, device=dev), torch.zeros(2, 8, 8, 8, device=dev))
+    with pytest.raises(RuntimeError, match="10002"):  # per-output kernel: square tap counts or a 1-D pass
+        H.resample2d(img, torch.empty(2, 8, 8, 8, device=dev, dtype=torch.bfloat16),
+                     torch.zeros(8, dtype=torch.int32, device=dev), torch.ones(8, 2, device=dev),
+                     torch.zeros(8, dtype=torch.int32, device=dev), torch.ones(8, 3, device=dev), 2, 3, 0, 0)
+    w = torch.zeros(8, 8, 3, 3, device=dev)
+    with pytest.raises(RuntimeError, match="10001"):  # q and qt come as a pair
+        H.prepare_weights(w, torch.empty(8, 3, 3, 8, device=dev), torch.empty(8, 3, 3, 8, device=dev, dtype=torch.bfloat16),
+                          torch.empty(8, 3, 3, 8, device=dev, dtype=torch.bfloat16), torch.empty(8, 8, device=dev), None, 0.1)
