@@ -173,3 +173,37 @@ def test_steps_run_with_augmentation_active():
                                        prints, marks, ada)
         assert all(np.isfinite(v) for v in (d_loss, g_loss, *parts))
     assert not torch.equal(before, nets["G"].decoder[-2].weight.weight.detach())
+
+
+@pytest.mark.parametrize("n,m0,m1", [(256, 107, 110), (40, 0, 0), (33, 5, 31), (64, 63, 63), (8, 7, 0)])
+def test_vectorised_operator_construction_matches_dense(n, m0, m1):
+    """banded_coo (COO triplets, vectorised) == banded (dense matrix, row loops) for the per-call
+    operators of the pipe, including margins as large as the image."""
+    from one_to_many_gan_amd import ada as P
+    from one_to_many_gan_amd import resample as R
+
+    op = P._pad_up_coo(n, m0, m1)
+    s1, w1, t1 = R.banded(P._dense(op))
+    s2, w2, t2 = R.banded_coo(*op)
+    assert t1 == t2 and np.array_equal(s1, s2) and np.allclose(w1, w2, atol=1e-7)
+    L = n + m0 + m1
+    opt = P._up_t_coo(L)
+    assert np.allclose(P._dense(opt), P._up_operator(L).T)
+    s1, w1, t1 = R.banded(P._dense(opt))
+    s2, w2, t2 = R.banded_coo(*opt)
+    assert t1 == t2 and np.array_equal(s1, s2) and np.allclose(w1, w2, atol=1e-7)
+    # interior rows sum to 2 x (one polyphase of the normalised filter) = 1: constants are preserved
+    # (the first / last rows lose taps to the zero extension of the upsampler, as in the published pipe)
+    rows = P._dense(op).sum(axis=1)
+    assert np.allclose(rows[6:-6], 1.0, atol=1e-6)
+
+
+def test_margins_stay_inside_the_image_for_extreme_transforms():
+    from one_to_many_gan_amd import ada as P
+
+    aug = _pipe(3, 1.0)
+    for seed in range(20):
+        aug.generator.manual_seed(seed)
+        g = aug.geometry_matrix(aug.draw(8), 64, 48)
+        mx0, my0, mx1, my1 = aug.margins(g, 64, 48)
+        assert 0 <= mx0 <= 63 and 0 <= mx1 <= 63 and 0 <= my0 <= 47 and 0 <= my1 <= 47

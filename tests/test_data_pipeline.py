@@ -136,3 +136,19 @@ def test_device_loader_feeds_the_step_without_a_layout_pass(tmp_path):
         assert len(first3) == 3
     finally:
         o2m.set_precision("bf16")
+
+
+def test_every_image_is_served_once_per_epoch():
+    from one_to_many_gan_amd.data import datasets as D
+
+    class Pool:
+        def __len__(self):
+            return 37
+
+    loader = D.DeviceLoader(Pool(), 5, generator=torch.Generator().manual_seed(9), drop_last=False)
+    for _ in range(3):  # a fresh permutation per epoch
+        idx = torch.cat([p[0] for p in loader.plan()]).tolist()
+        assert sorted(idx) == list(range(37))
+    dropped = D.DeviceLoader(Pool(), 5, generator=torch.Generator().manual_seed(9))
+    idx = torch.cat([p[0] for p in dropped.plan()]).tolist()
+    assert len(idx) == 35 and len(set(idx)) == 35
