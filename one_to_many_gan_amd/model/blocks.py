@@ -34,15 +34,14 @@ class ResnetBlock(nn.Module):
     def __init__(self, dim: int, *, use_bias: bool = False):
         super().__init__()
         self.dim = dim
+        def conv3():
+            return EqualisedConv2d(dim, dim, 3, padding=0, use_bias=use_bias)
+
+        # slots 0..6 as in the reference Sequential: pad, CONV, norm, relu, pad, CONV, norm
         self.conv_block = nn.Sequential(
-            _Slot("ReflectionPad2d(1) -> conv loader"),
-            EqualisedConv2d(dim, dim, kernel_size=3, padding=0, use_bias=use_bias),
-            _Slot("InstanceNorm2d -> instnorm kernels"),
-            _Slot("ReLU -> instnorm apply"),
-            _Slot("ReflectionPad2d(1) -> conv loader"),
-            EqualisedConv2d(dim, dim, kernel_size=3, padding=0, use_bias=use_bias),
-            _Slot("InstanceNorm2d (+ residual add) -> instnorm kernels"),
-        )
+            _Slot("ReflectionPad2d(1) -> conv loader"), conv3(), _Slot("InstanceNorm2d -> instnorm kernels"),
+            _Slot("ReLU -> instnorm apply"), _Slot("ReflectionPad2d(1) -> conv loader"), conv3(),
+            _Slot("InstanceNorm2d (+ residual add) -> instnorm kernels"))
 
     def run(self, t):
         u = self.conv_block[1].run(t, reflect=1)
@@ -61,13 +60,13 @@ class ModulatedResnetBlock(nn.Module):
     def __init__(self, dim: int, w_dim: int, *, use_bias: bool = False):
         super().__init__()
         self.dim = dim
+        def modconv3():
+            return Conv2dWeightModulate(dim, dim, 3, w_dim, 0, use_bias=use_bias)
+
+        # slots 0..4 as in the reference ModuleList: pad, MODCONV, relu, pad, MODCONV
         self.conv_block = nn.ModuleList([
-            _Slot("ReflectionPad2d(1) -> conv loader"),
-            Conv2dWeightModulate(dim, dim, w_dim=w_dim, kernel_size=3, padding=0, use_bias=use_bias),
-            _Slot("ReLU -> conv epilogue"),
-            _Slot("ReflectionPad2d(1) -> conv loader"),
-            Conv2dWeightModulate(dim, dim, w_dim=w_dim, kernel_size=3, padding=0, use_bias=use_bias),
-        ])
+            _Slot("ReflectionPad2d(1) -> conv loader"), modconv3(), _Slot("ReLU -> conv epilogue"),
+            _Slot("ReflectionPad2d(1) -> conv loader"), modconv3()])
 
     def run(self, t, w):
         u = self.conv_block[1].run(t, w, reflect=1, act=H.ACT_RELU)

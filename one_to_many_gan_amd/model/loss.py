@@ -11,32 +11,34 @@ from .. import ops
 
 
 class ADAp:
-    """Adaptive-discriminator-augmentation probability (reference loss.py:11-52): a host
-    state machine fed one 0-dim score per discriminator step.  Scores are kept as device
-    tensors; nothing here forces a device sync until ``__call__`` is asked for the float."""
+    """Controller of the augmentation probability (reference loss.py:11-52).
+
+    Every ``window = ada_e // batch_size`` discriminator steps the mean of the collected
+    ``sign(D(real))`` scores is compared with the target: below it p drops by
+    ``ada_adjustment_size * ada_e``, above it p rises by the same amount, and p never goes
+    negative (there is no upper clamp in the reference either).  Reference quirk kept: the score
+    that closes a window is counted in that window AND opens the next one (loss.py:34,49).
+    Scores stay device tensors; only ``__call__`` (one ``.item()``) synchronises.
+    ``p`` / ``curr_batch`` / ``mean_real_scores`` are the state the checkpoint code saves."""
 
     def __init__(self, ada_e: float, ada_adjustment_size: float, batch_size: int,
                  discriminator_overfitting_target: float):
-        self.n_batches = ada_e // batch_size
-        self.ada_adjustment = ada_adjustment_size * ada_e
-        self.overfitting_target = discriminator_overfitting_target
+        self.window, self.step, self.target = ada_e // batch_size, ada_adjustment_size * ada_e, \
+            discriminator_overfitting_target
         self.p = torch.zeros(())
-        self.curr_batch = 0
-        self.mean_real_scores = []
+        self.curr_batch, self.mean_real_scores = 0, []
+
+    def _adjust(self):
+        scores = torch.stack([t.detach().float().cpu() for t in self.mean_real_scores])
+        verdict = scores.mean()
+        delta = self.step if verdict > self.target else (-self.step if verdict < self.target else 0.0)
+        self.p = torch.clamp_min(self.p + delta, 0.0)
 
     def update_p(self, mean_score: torch.Tensor):
-        window_closes = self.curr_batch == self.n_batches
         self.mean_real_scores.append(mean_score)
-        if window_closes:
-            mean_sign = torch.stack([s.detach().float().cpu() for s in self.mean_real_scores]).mean()
-            if mean_sign < self.overfitting_target:
-                self.p = self.p - self.ada_adjustment
-            elif mean_sign > self.overfitting_target:
-                self.p = self.p + self.ada_adjustment
-            self.p = torch.clamp_min(self.p, 0.0)
-            # the score that closed the window also opens the next one (reference loss.py:34,49)
-            self.mean_real_scores = [mean_score]
-            self.curr_batch = 0
+        if self.curr_batch == self.window:
+            self._adjust()
+            self.mean_real_scores, self.curr_batch = [mean_score], 0
         self.curr_batch += 1
 
     def __call__(self) -> float:
