@@ -1,6 +1,17 @@
-"""ctypes binding of libo2m_hip.so (the C ABI declared in include/o2m_hip.h).
+"""Host binding of the HIP kernels.
 
-There is NO fallback: if the library is missing or a call is made without a GPU tensor the
+Two shared objects, both built in-tree by build.py:
+
+* ``lib/libo2m_hip.so``   -- the kernels behind the C ABI of include/o2m_hip.h (torch-free);
+* ``lib/libo2m_torch.so`` -- csrc/torch_ops.cpp: ``TORCH_LIBRARY(o2m, ...)``, one dispatcher-visible
+  op per launcher (``torch.ops.o2m.conv2d_fwd`` ...) with CUDA and Meta kernels.  Each op checks its
+  tensors, takes the current HIP stream of their device under a device guard and calls the C ABI.
+
+The wrappers below are what ops.py calls: they only pick the op and label the launch for
+bench.py's HIP-event profile.  ``SIGNATURES`` (ctypes) mirrors the header one for one and is used
+to verify at load time that the C library exports every declared symbol.
+
+There is NO fallback: if a library is missing or a call is made without a GPU tensor the
 import / call raises.  The product path never routes through PyTorch eager kernels for the
 ops declared in the header, and never through the CPU oracle.
 """
@@ -15,6 +26,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # O2M_HIP_LIB: alternative build of the same ABI (kernel A/B experiments only)
 LIB_PATH = os.environ.get("O2M_HIP_LIB") or os.path.join(_HERE, "lib", "libo2m_hip.so")
+TORCH_LIB_PATH = os.path.join(_HERE, "lib", "libo2m_torch.so")
 
 BF16, F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
@@ -125,7 +137,7 @@ def _timed(name, flops, tensor, launch):
 
 
 def lib():
-    """Load the shared library (once).  Raises if it has not been built."""
+    """Load the C-ABI library (once) and check its exports.  Raises if it has not been built."""
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
@@ -134,7 +146,7 @@ def lib():
                 "(run `python -m one_to_many_gan_amd.build` or __graft_entry__.build()). "
                 "There is no CPU or eager fallback."
             )
-        handle = C.CDLL(LIB_PATH)
+        handle = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)  # the torch shim binds to these symbols
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the symbol is not exported
             fn.restype, fn.argtypes = res, args
@@ -142,6 +154,24 @@ def lib():
             raise RuntimeError("libo2m_hip.so ABI version mismatch: rebuild the extension")
         _lib = handle
     return _lib
+
+
+_ops = None
+
+
+def ops():
+    """``torch.ops.o2m`` (loads libo2m_torch.so once).  Raises if it has not been built."""
+    global _ops
+    if _ops is None:
+        lib()  # the C ABI first: the shim's undefined symbols resolve against it
+        if not os.path.exists(TORCH_LIB_PATH):
+            raise RuntimeError(f"{TORCH_LIB_PATH} is missing: run `python -m one_to_many_gan_amd.build`. "
+                               "There is no CPU or eager fallback.")
+        torch.ops.load_library(TORCH_LIB_PATH)
+        if torch.ops.o2m.abi_version() != ABI_VERSION:
+            raise RuntimeError("libo2m_torch.so was built against another libo2m_hip.so: rebuild")
+        _ops = torch.ops.o2m
+    return _ops
 
 
 def dtype_code(dt: torch.dtype) -> int:
@@ -152,11 +182,8 @@ def dtype_code(dt: torch.dtype) -> int:
     raise TypeError(f"unsupported activation dtype {dt}")
 
 
-def _stream(t: torch.Tensor):
-    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
-
-
 def ptr(t):
+    """Raw device pointer for direct ctypes calls of the C ABI (tests/test_kernels_gpu.py)."""
     if t is None:
         return None
     if not t.is_cuda:
@@ -164,6 +191,10 @@ def ptr(t):
     if not t.is_contiguous():
         raise RuntimeError("o2m HIP op needs contiguous tensors")
     return C.c_void_p(t.data_ptr())
+
+
+def _stream(t: torch.Tensor):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
 def check(err: int, what: str):
@@ -176,185 +207,117 @@ def check(err: int, what: str):
 
 def conv2d_fwd(x, w, y, *, in_scale=None, out_scale=None, bias=None, residual=None, pad, pad_mode, act,
                per_sample_w=False, stride=1):
-    B, H, W, Ci = x.shape
-    Co, KH, KW, _ = w.shape[-4:]
-    wstride = Co * KH * KW * Ci if per_sample_w else 0
-    d = ConvDesc(ptr(x), ptr(w), ptr(y), ptr(in_scale), ptr(out_scale), ptr(bias), ptr(residual),
-                 B, H, W, Ci, Co, KH, KW, pad, pad_mode, act, dtype_code(x.dtype), wstride, stride)
-    flops = 2.0 * y.shape[0] * y.shape[1] * y.shape[2] * Co * KH * KW * Ci
-    _timed(_igemm_name(x.dtype, Co, in_scale is not None, y.shape[0] * y.shape[1] * y.shape[2], KH * KW * Ci),
-           flops, x,
-           lambda: check(lib().o2m_conv2d_fwd(C.byref(d), _stream(x)), "o2m_conv2d_fwd"))
+    if PROFILE is None:
+        return ops().conv2d_fwd(x, w, y, in_scale, out_scale, bias, residual, pad, pad_mode, act, per_sample_w, stride)
+    Co, KH, KW, Ci = w.shape[-4:]
+    m = y.shape[0] * y.shape[1] * y.shape[2]
+    _timed(_igemm_name(x.dtype, Co, in_scale is not None, m, KH * KW * Ci), 2.0 * m * Co * KH * KW * Ci, x,
+           lambda: ops().conv2d_fwd(x, w, y, in_scale, out_scale, bias, residual, pad, pad_mode, act, per_sample_w,
+                                    stride))
 
 
 def conv2d_wgrad(x, gy, dw, *, in_scale=None, gy_scale=None, pad, pad_mode, splits=0, more=(), stride=1):
     """``more``: extra (x, gy) pairs of the same shape reduced by the same launch (<= 7)."""
-    B, H, W, Ci = x.shape
-    Co, KH, KW, _ = dw.shape
-    d = WgradDesc(ptr(x), ptr(gy), ptr(dw), ptr(in_scale), ptr(gy_scale), B, H, W, Ci, Co, KH, KW,
-                  pad, pad_mode, dtype_code(x.dtype), splits, 1 + len(more), stride)
-    for i, (xi, gi) in enumerate(more, start=1):
-        if xi.shape != x.shape or gi.shape != gy.shape or xi.dtype != x.dtype:
-            raise RuntimeError("wgrad segments must share one shape")
-        d.x_seg[i], d.gy_seg[i] = xi.data_ptr(), gi.data_ptr()
-        ptr(xi), ptr(gi)  # contiguity / device checks
-    flops = 2.0 * (1 + len(more)) * gy.shape[0] * gy.shape[1] * gy.shape[2] * Co * KH * KW * Ci
-    _timed(_wgrad_name(x.dtype, Co, (1 + len(more)) * gy.shape[0] * gy.shape[1] * gy.shape[2], KH * KW * Ci), flops, x,
-           lambda: check(lib().o2m_conv2d_wgrad(C.byref(d), _stream(x)), "o2m_conv2d_wgrad"))
+    mx, mg = [p[0] for p in more], [p[1] for p in more]
+    if PROFILE is None:
+        return ops().conv2d_wgrad(x, gy, dw, in_scale, gy_scale, pad, pad_mode, splits, mx, mg, stride)
+    Co, KH, KW, Ci = dw.shape
+    m = (1 + len(more)) * gy.shape[0] * gy.shape[1] * gy.shape[2]
+    _timed(_wgrad_name(x.dtype, Co, m, KH * KW * Ci), 2.0 * m * Co * KH * KW * Ci, x,
+           lambda: ops().conv2d_wgrad(x, gy, dw, in_scale, gy_scale, pad, pad_mode, splits, mx, mg, stride))
 
 
 def act_bwd_reduce(g, y, residual, out_mul, gu, sums, act):
-    B, P, Cn = g.shape[0], g.shape[1] * g.shape[2], g.shape[3]
-    check(lib().o2m_act_bwd_reduce(ptr(g), ptr(y), ptr(residual), ptr(out_mul), ptr(gu), ptr(sums), B, P,
-                                   Cn, act, dtype_code(g.dtype), _stream(g)), "o2m_act_bwd_reduce")
+    ops().act_bwd_reduce(g, y, residual, out_mul, gu, sums, act)
 
 
 def style_fwd(w, ws, bs, qt, s, d, ci, cs, eps):
-    B, WD = w.shape
-    cip = s.shape[1]
-    cop = d.shape[1] if d is not None else 0
-    check(lib().o2m_style_fwd(ptr(w), ptr(ws), ptr(bs), ptr(qt), ptr(s), ptr(d), B, WD, ci, cip, cop, cs,
-                              eps, _stream(s)), "o2m_style_fwd")
+    ops().style_fwd(w, ws, bs, qt, s, d, ci, cs, eps)
 
 
 def style_bwd(sums, bias, dots, s, d, q, w, ws, e, gs, gw, gws, gbs, gq, ci, cs, accumulate=False):
-    B, WD = w.shape
-    cip = s.shape[1]
-    cop = d.shape[1] if d is not None else 8
-    check(lib().o2m_style_bwd(ptr(sums), ptr(bias), ptr(dots), ptr(s), ptr(d), ptr(q), ptr(w), ptr(ws),
-                              ptr(e), ptr(gs), ptr(gw), ptr(gws), ptr(gbs), ptr(gq), B, WD, ci, cip, cop, cs,
-                              int(bool(accumulate)), _stream(s)), "o2m_style_bwd")
+    ops().style_bwd(sums, bias, dots, s, d, q, w, ws, e, gs, gw, gws, gbs, gq, ci, cs, bool(accumulate))
 
 
 def wgrad_finalize(acc, gq, w32, grad, co, ci, c):
-    cop, kh, kw, cip = acc.shape
-    check(lib().o2m_wgrad_finalize(ptr(acc), ptr(gq), ptr(w32), ptr(grad), co, ci, kh * kw, cop, cip, c,
-                                   _stream(acc)), "o2m_wgrad_finalize")
+    ops().wgrad_finalize(acc, gq, w32, grad, co, ci, c)
 
 
 def prepare_weights(w, full, w_f, w_d, q, qt, c):
     """W*c in the kernel layouts (see o2m_prepare_weights); ``w`` is the raw (Co,Ci,KH,KW) parameter."""
-    Co, Ci, KH, KW = w.shape
-    Cop, _, _, Cip = full.shape
-    check(lib().o2m_prepare_weights(ptr(w), ptr(full), ptr(w_f), ptr(w_d), ptr(q), ptr(qt), Co, Ci, KH * KW,
-                                    Cop, Cip, c, dtype_code(w_f.dtype), _stream(w)), "o2m_prepare_weights")
+    ops().prepare_weights(w, full, w_f, w_d, q, qt, c)
 
 
 def modulate_weights(w32, s, out):
     """out[b,o,kh,kw,i] = w32[o,kh,kw,i] * s[b,i] in the dtype of ``out``."""
-    Co, KH, KW, Ci = w32.shape
-    check(lib().o2m_modulate_weights(ptr(w32), ptr(s), ptr(out), s.shape[0], Co, KH * KW, Ci,
-                                     dtype_code(out.dtype), _stream(out)), "o2m_modulate_weights")
+    ops().modulate_weights(w32, s, out)
 
 
 def fold_scale_dot(gpad, x, scale, gx, dots, pad, xs=None):
-    B, H, W, Cn = gx.shape
-    check(lib().o2m_fold_scale_dot(ptr(gpad), ptr(x), ptr(scale), ptr(gx), ptr(dots), ptr(xs), B, H, W, Cn,
-                                   pad, dtype_code(gx.dtype), _stream(gx)), "o2m_fold_scale_dot")
+    ops().fold_scale_dot(gpad, x, scale, gx, dots, pad, xs)
 
 
 def instnorm_ws_floats(B, P, Cn):
-    return int(lib().o2m_instnorm_ws_floats(B, P, Cn))
+    return ops().instnorm_ws_floats(B, P, Cn)
 
 
 def instnorm_stats(x, partial, mean_rstd, eps):
-    B, P, Cn = x.shape[0], x.shape[1] * x.shape[2], x.shape[3]
-    check(lib().o2m_instnorm_stats(ptr(x), ptr(partial), ptr(mean_rstd), B, P, Cn, eps,
-                                   dtype_code(x.dtype), _stream(x)), "o2m_instnorm_stats")
+    ops().instnorm_stats(x, partial, mean_rstd, eps)
 
 
 def instnorm_apply(x, mean_rstd, residual, y, act):
-    B, P, Cn = x.shape[0], x.shape[1] * x.shape[2], x.shape[3]
-    check(lib().o2m_instnorm_apply(ptr(x), ptr(mean_rstd), ptr(residual), ptr(y), B, P, Cn, act,
-                                   dtype_code(x.dtype), _stream(x)), "o2m_instnorm_apply")
+    ops().instnorm_apply(x, mean_rstd, residual, y, act)
 
 
 def instnorm_bwd(g, x, mean_rstd, partial, gsums, gx, act):
-    B, P, Cn = x.shape[0], x.shape[1] * x.shape[2], x.shape[3]
-    check(lib().o2m_instnorm_bwd(ptr(g), ptr(x), ptr(mean_rstd), ptr(partial), ptr(gsums), ptr(gx), B, P,
-                                 Cn, act, dtype_code(x.dtype), _stream(x)), "o2m_instnorm_bwd")
+    ops().instnorm_bwd(g, x, mean_rstd, partial, gsums, gx, act)
 
 
 def resample2d(x, y, sy, wy, sx, wx, ty, tx=None, span_y=0, span_x=0):
     """``ty`` / ``tx``: taps per axis (wy is [Ho][ty], wx is [Wo][tx]); spans: see resample.Taps."""
-    B, H, W, Cn = x.shape
-    _, Ho, Wo, _ = y.shape
-    tx = ty if tx is None else tx
-    check(lib().o2m_resample2d(ptr(x), ptr(y), ptr(sy), ptr(wy), ptr(sx), ptr(wx), B, H, W, Ho, Wo, Cn,
-                               ty, tx, span_y, span_x, dtype_code(x.dtype), _stream(x)), "o2m_resample2d")
+    ops().resample2d(x, y, sy, wy, sx, wx, ty, ty if tx is None else tx, span_y, span_x)
 
 
 def ada_grid_sample(x, theta, y):
-    B, Hs, Ws, Cp = x.shape
-    _, Ho, Wo, _ = y.shape
-    check(lib().o2m_ada_grid_sample(ptr(x), ptr(theta), ptr(y), B, Hs, Ws, Ho, Wo, Cp, dtype_code(x.dtype),
-                                    _stream(x)), "o2m_ada_grid_sample")
+    ops().ada_grid_sample(x, theta, y)
 
 
 def ada_grid_sample_bwd(gy, theta, gx):
-    B, Ho, Wo, Cp = gy.shape
-    _, Hs, Ws, _ = gx.shape
-    if gx.dtype != gy.dtype:
-        raise RuntimeError("ada_grid_sample_bwd: gx and gy share one dtype")
-    check(lib().o2m_ada_grid_sample_bwd(ptr(gy), ptr(theta), ptr(gx), B, Hs, Ws, Ho, Wo, Cp, dtype_code(gy.dtype),
-                                        _stream(gy)), "o2m_ada_grid_sample_bwd")
+    ops().ada_grid_sample_bwd(gy, theta, gx)
 
 
 def reflect_fold(gpad, gx, pad_top, pad_left):
-    B, Hp, Wp, Cp = gpad.shape
-    _, Hh, Ww, _ = gx.shape
-    check(lib().o2m_reflect_fold(ptr(gpad), ptr(gx), B, Hh, Ww, Hp, Wp, pad_top, pad_left, Cp,
-                                 dtype_code(gpad.dtype), dtype_code(gx.dtype), _stream(gx)), "o2m_reflect_fold")
+    ops().reflect_fold(gpad, gx, pad_top, pad_left)
 
 
 def ada_colour(x, m, y, c):
-    B, Hh, Ww, Cp = x.shape
-    check(lib().o2m_ada_colour(ptr(x), ptr(m), ptr(y), B, Hh * Ww, c, Cp, dtype_code(x.dtype), _stream(x)),
-          "o2m_ada_colour")
+    ops().ada_colour(x, m, y, c)
 
 
 def gather_images(pool, index, flip, out):
     """Batch from the HBM-resident uint8 pool (see o2m_gather_images)."""
-    N, H, W, Cn = pool.shape
-    B, _, _, Cp = out.shape
-    if pool.dtype != torch.uint8 or index.dtype != torch.int32 or flip.dtype != torch.uint8:
-        raise RuntimeError("gather_images: pool uint8, index int32, flip uint8")
-    if index.shape[0] != B or flip.shape[0] != B or out.shape[1:3] != pool.shape[1:3]:
-        raise RuntimeError("gather_images: shape mismatch")
-    check(lib().o2m_gather_images(ptr(pool), ptr(index), ptr(flip), ptr(out), N, B, H, W, Cn, Cp,
-                                  dtype_code(out.dtype), _stream(out)), "o2m_gather_images")
+    ops().gather_images(pool, index, flip, out)
 
 
 def pack_nchw(src, dst):
-    B, Cn, H, W = src.shape
-    check(lib().o2m_pack_nchw(ptr(src), ptr(dst), B, Cn, H, W, dst.shape[3], dtype_code(dst.dtype),
-                              _stream(dst)), "o2m_pack_nchw")
+    ops().pack_nchw(src, dst)
 
 
 def unpack_nhwc(src, dst):
-    B, Cn, H, W = dst.shape
-    check(lib().o2m_unpack_nhwc(ptr(src), ptr(dst), B, Cn, H, W, src.shape[3], dtype_code(src.dtype),
-                                _stream(src)), "o2m_unpack_nhwc")
+    ops().unpack_nhwc(src, dst)
 
 
 def reduce_blocks(n):
-    return int(lib().o2m_reduce_blocks(n))
+    return ops().reduce_blocks(n)
 
 
 def reduce_fwd(a, b, w, partials, mode):
-    B = a.shape[0]
-    nps = a.numel() // B
-    check(lib().o2m_reduce_fwd(ptr(a), ptr(b), ptr(w), ptr(partials), B, nps, mode, dtype_code(a.dtype),
-                               _stream(a)), "o2m_reduce_fwd")
+    ops().reduce_fwd(a, b, w, partials, mode)
 
 
 def reduce_bwd(a, b, w, coef, ga, mode):
-    B = a.shape[0]
-    nps = a.numel() // B
-    check(lib().o2m_reduce_bwd(ptr(a), ptr(b), ptr(w), ptr(coef), ptr(ga), B, nps, mode,
-                               dtype_code(a.dtype), _stream(a)), "o2m_reduce_bwd")
+    ops().reduce_bwd(a, b, w, coef, ga, mode)
 
 
 def adam_step(p, g, m, v, step, lr, beta1, beta2, eps, grad_scale):
-    check(lib().o2m_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), ptr(step), p.numel(), lr, beta1, beta2,
-                              eps, grad_scale, _stream(p)), "o2m_adam_step")
+    ops().adam_step(p, g, m, v, step, lr, beta1, beta2, eps, grad_scale)

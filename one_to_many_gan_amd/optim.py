@@ -77,14 +77,54 @@ class FusedAdam:
         ops.bump_weights_epoch()
 
     def state_dict(self):
-        return {"step": self.step_t.clone(), "exp_avg": self.exp_avg.clone(),
-                "exp_avg_sq": self.exp_avg_sq.clone(), "lr": self.lr, "betas": self.betas,
-                "eps": self.eps}
+        """``torch.optim.Adam.state_dict()`` layout (what the reference checkpoints,
+        evaluation.py:247-254): per-parameter ``step`` / ``exp_avg`` / ``exp_avg_sq`` keyed by
+        the parameter's position in ``module.parameters()`` order, plus one param group.  The
+        moments are copies of the parameter's slice of the flat buckets."""
+        state = {}
+        step = self.step_t.detach().reshape(()).clone()
+        for i, (p, o) in enumerate(zip(self.bucket.params, self.bucket.offsets)):
+            state[i] = {"step": step.clone(),
+                        "exp_avg": self.exp_avg[o: o + p.numel()].view_as(p).clone(),
+                        "exp_avg_sq": self.exp_avg_sq[o: o + p.numel()].view_as(p).clone()}
+        group = {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": 0, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
+                 "fused": None, "decoupled_weight_decay": False,
+                 "params": list(range(len(self.bucket.params)))}
+        return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
-        self.step_t.copy_(sd["step"])
-        self.exp_avg.copy_(sd["exp_avg"])
-        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        """Accepts the ``torch.optim.Adam`` layout (ours, or a reference checkpoint's) and the
+        flat layout this class wrote in round 1 (``step`` / ``exp_avg`` / ``exp_avg_sq`` buckets)."""
+        if "state" not in sd:  # round-1 flat layout
+            self.step_t.copy_(torch.as_tensor(sd["step"]).reshape(1))
+            self.exp_avg.copy_(sd["exp_avg"])
+            self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+            return
+        state = sd["state"]
+        n = len(self.bucket.params)
+        if state and (len(state) != n or sorted(int(k) for k in state) != list(range(n))):
+            raise ValueError(f"optimiser state covers {len(state)} parameters, this network has {n}")
+        steps = set()
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        for k, st in state.items():
+            i = int(k)
+            p, o = self.bucket.params[i], self.bucket.offsets[i]
+            if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                raise ValueError(f"optimiser state {i}: shape {tuple(st['exp_avg'].shape)} != {tuple(p.shape)}")
+            self.exp_avg[o: o + p.numel()].view_as(p).copy_(st["exp_avg"])
+            self.exp_avg_sq[o: o + p.numel()].view_as(p).copy_(st["exp_avg_sq"])
+            steps.add(float(st["step"]))
+        if len(steps) > 1:
+            raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): one fused step counter")
+        self.step_t.fill_(steps.pop() if steps else 0.0)
+        groups = sd.get("param_groups") or []
+        if groups:
+            g = groups[0]
+            self.lr = float(g.get("lr", self.lr))
+            self.betas = tuple(float(b) for b in g.get("betas", self.betas))
+            self.eps = float(g.get("eps", self.eps))
 
 
 def make_adam(module: torch.nn.Module, lr: float, betas=(0.9, 0.999)) -> FusedAdam:
