@@ -11,10 +11,11 @@ from __future__ import annotations
 
 import torch
 
-from .ops import compute_dtype, set_precision  # noqa: F401
+from . import ops  # noqa: F401
+from .ops import compute_dtype, set_deterministic, set_precision  # noqa: F401
 from .optim import FusedAdam, make_adam  # noqa: F401
 
-__all__ = ["set_precision", "compute_dtype", "make_adam", "FusedAdam", "IdentityADA", "AdaptiveDiscriminatorAugmentation",
+__all__ = ["set_precision", "set_deterministic", "compute_dtype", "make_adam", "FusedAdam", "IdentityADA", "AdaptiveDiscriminatorAugmentation",
            "REFERENCE_ADA_SWITCHES"]
 
 # the switches the reference constructs its augmentation with (train.py:175-188)

@@ -29,6 +29,17 @@ def set_precision(precision: str) -> None:
     _STATE["dtype"] = torch.bfloat16 if precision == "bf16" else torch.float32
 
 
+def set_deterministic(flag: bool) -> None:
+    """The reference's ``deterministic_cuda_kernels`` switch (train.py:41-45, config.toml:9): when on,
+    every kernel that sums across workgroups with float atomics takes its two-stage, fixed-order
+    form instead, so two runs of a step are bitwise equal."""
+    _STATE["deterministic"] = bool(flag)
+
+
+def deterministic() -> bool:
+    return bool(_STATE.get("deterministic", False))
+
+
 def compute_dtype() -> torch.dtype:
     return _STATE["dtype"]
 
@@ -126,18 +137,49 @@ class PreparedWeight:
         self.uses = []  # deferred (x, gy, pad, pad_mode) of this backward pass
         self.dw2_acc = None  # space-to-depth form of dw_acc (s2d_wgrad), folded at finalize
         self.dw2_used = False
+        # forward applications recorded for a backward that wants this filter's gradient, and how
+        # many of them the running backward has reduced: when they meet, the layer is finalised on
+        # the spot (its gradient is complete) instead of at the end of backward
+        self.fwd_uses = 0
+        self.bwd_uses = 0
 
     def accumulators(self, device):
         if self.dw_acc is None or self.dw_acc.device != device:
             self.dw_acc = torch.zeros((self.cop, self.kh, self.kw, self.cip), dtype=torch.float32, device=device)
             self.gq_acc = (torch.zeros((self.cop, self.cip), dtype=torch.float32, device=device)
                            if self.need_q else None)
+        _enter_backward_pass()
         if not self.pending:
             self.pending = True
-            if not _PENDING:
-                torch.autograd.Variable._execution_engine.queue_callback(_finalize_weight_grads)
             _PENDING.append(self)
         return self.dw_acc, self.gq_acc
+
+    def note_forward_use(self, wants_weight_grad: bool) -> bool:
+        """Forward side of the use count.  ``wants_weight_grad`` = ``ctx.needs_input_grad[<weight>]``
+        of the calling autograd Function (grad mode itself reads as off inside ``forward``)."""
+        if wants_weight_grad:
+            self.fwd_uses += 1
+        return bool(wants_weight_grad)
+
+    def use_reduced(self, device):
+        """Backward side: one counted application's weight gradient (and dL/dQ) has been added to
+        the accumulators.  When it was the last one recorded, the gradient is complete NOW, not at
+        the end of backward: finalise the layer, so the data-parallel reducer can start the bucket
+        segment's all-reduce under the rest of backward (dist.BucketReducer)."""
+        self.bwd_uses += 1
+        if self.bwd_uses == self.fwd_uses and _EARLY_FINALIZE:
+            wst = _wgrad_stream(device)
+            if wst is not None:
+                torch.cuda.current_stream(device).wait_stream(wst)
+            _finalize_layer(self)
+
+    def discard_partial(self):
+        """Drop what an aborted backward pass left behind (see _enter_backward_pass)."""
+        for t in (self.dw_acc, self.gq_acc, self.dw2_acc):
+            if t is not None:
+                t.zero_()
+        self.uses, self.pending, self.dw2_used = [], False, False
+        self.fwd_uses = self.bwd_uses = 0
 
     S2D = 4  # output pixels per side folded into channels by the space-to-depth form
 
@@ -231,6 +273,8 @@ _DIRECT_STYLE_GRADS = _os.environ.get("O2M_DIRECT_STYLE_GRADS", "0") == "1"
 # _finalize_weight_grads needs them), so they can run on their own stream next to the HBM-bound
 # pointwise kernels of the following layers.
 _WGRAD_STREAM = _os.environ.get("O2M_WGRAD_STREAM", "0") == "1"
+# O2M_EARLY_FINALIZE=0 falls back to finalising every filter gradient in the end-of-backward callback
+_EARLY_FINALIZE = _os.environ.get("O2M_EARLY_FINALIZE", "1") == "1"
 _WSTREAM: dict = {}
 
 
@@ -251,6 +295,27 @@ def _side_stream(device):
         st = _SIDE[device] = torch.cuda.Stream(device=device)
     return st
 _PENDING: list = []
+_PASS = {"task": None}
+
+
+def _enter_backward_pass():
+    """Called by every weight-gradient producer.  One end-of-backward callback is queued per
+    autograd graph task (identified by the engine's task id), not "whenever the pending list is
+    empty": a backward that raised leaves the list non-empty and its callback is dropped by the
+    engine, which in round 1 meant that no later backward ever finalised a filter gradient again.
+    Entering a new task with leftovers from a dead one discards them first."""
+    task = torch._C._current_graph_task_id()
+    if task == _PASS["task"]:
+        return
+    if _PENDING:  # a previous backward died before its callback ran
+        for prep in _PENDING:
+            prep.discard_partial()
+        _PENDING.clear()
+    _PASS["task"] = task
+    if task >= 0:
+        torch.autograd.Variable._execution_engine.queue_callback(_finalize_weight_grads)
+
+
 # parameter -> callable(param), invoked when that filter's gradient has been written by
 # _finalize_weight_grads (the data-parallel reducer counts these like autograd's own
 # post-accumulate hooks, which never fire for the filters)
@@ -271,33 +336,42 @@ def _run_deferred_wgrads(prep):
             H.conv2d_wgrad(chunk[0][0], chunk[0][1], prep.dw_acc, pad=pad, pad_mode=pad_mode, more=chunk[1:])
 
 
+def _finalize_layer(prep):
+    """Kernel-layout accumulators of one layer -> ``weight.grad`` (+= like autograd), clears them,
+    and tells the data-parallel reducer that this filter's gradient is complete."""
+    prep.pending = False
+    prep.fwd_uses = prep.bwd_uses = 0
+    if prep.uses:
+        _run_deferred_wgrads(prep)
+    if prep.dw2_used:
+        prep.fold_s2d()
+    w = prep.weight
+    if w.grad is None:
+        w.grad = torch.zeros_like(w)
+    grad = w.grad
+    if not grad.is_contiguous() or grad.dtype != torch.float32:
+        tmp = torch.zeros(w.shape, dtype=torch.float32, device=w.device)
+        H.wgrad_finalize(prep.dw_acc, prep.gq_acc, prep.get()[3], tmp, prep.co, prep.ci, prep.c)
+        grad.add_(tmp.to(grad.dtype))
+    else:
+        H.wgrad_finalize(prep.dw_acc, prep.gq_acc, prep.get()[3], grad, prep.co, prep.ci, prep.c)
+    hook = GRAD_READY_HOOKS.get(w)
+    if hook is not None:
+        hook(w)
+
+
 def _finalize_weight_grads():
-    """Runs once at the end of every backward pass (autograd engine callback): runs the
-    deferred weight-gradient reductions and converts each touched layer's accumulated
-    kernel-layout gradient into ``weight.grad``."""
+    """End of a backward pass (autograd engine callback): finalises every layer that was not
+    already finalised when its last recorded use was reduced (``_ConvFn.backward``) -- e.g. a
+    layer whose forward ran more often than its backward (part of the graph unused)."""
     pend = list(_PENDING)
     _PENDING.clear()
+    _PASS["task"] = None
     for dev, wst in _WSTREAM.items():  # weight gradients reduced on their own stream
         torch.cuda.current_stream(dev).wait_stream(wst)
     for prep in pend:
-        prep.pending = False
-        if prep.uses:
-            _run_deferred_wgrads(prep)
-        if prep.dw2_used:
-            prep.fold_s2d()
-        w = prep.weight
-        if w.grad is None:
-            w.grad = torch.zeros_like(w)
-        grad = w.grad
-        if not grad.is_contiguous() or grad.dtype != torch.float32:
-            tmp = torch.zeros(w.shape, dtype=torch.float32, device=w.device)
-            H.wgrad_finalize(prep.dw_acc, prep.gq_acc, prep.get()[3], tmp, prep.co, prep.ci, prep.c)
-            grad.add_(tmp.to(grad.dtype))
-        else:
-            H.wgrad_finalize(prep.dw_acc, prep.gq_acc, prep.get()[3], grad, prep.co, prep.ci, prep.c)
-        hook = GRAD_READY_HOOKS.get(w)
-        if hook is not None:
-            hook(w)
+        if prep.pending:
+            _finalize_layer(prep)
 
 
 def _pad_cols(t: torch.Tensor, n: int) -> torch.Tensor:
@@ -364,6 +438,7 @@ class _ConvFn(torch.autograd.Function):
             H.conv2d_fwd(x, w_f, y, in_scale=s, out_scale=d, bias=bias_p, residual=residual,
                          pad=pad, pad_mode=pad_mode, act=act)
         ctx.prep, ctx.pad, ctx.pad_mode, ctx.act = prep, pad, pad_mode, act
+        ctx.counted = prep.note_forward_use(ctx.needs_input_grad[1])
         ctx.ts_params = (ts_weight, ts_bias)
         ctx.has_bias, ctx.has_res = bias is not None, residual is not None
         ctx.save_for_backward(x, y, residual, s, d, weight, bias_p, wv, ws)
@@ -489,17 +564,33 @@ class _ConvFn(torch.autograd.Function):
                 g_tw = g_tb = None  # already in .grad
         else:
             g_ws = g_tw = g_tb = None
+        if need_w and ctx.counted:  # after style_bwd above: it adds this use's dL/dQ
+            prep.use_reduced(dev)
         g_res = g if (ctx.has_res and need_res) else None
         return (g_x if need_x else None, None, g_bias, g_ws, g_tw, g_tb, g_res,
                 None, None, None, None, None, None)
+
+
+# Debug tap (None in production): a list that receives, in execution order, the sign mask of every
+# fused ReLU / LeakyReLU output as a CPU bool NCHW tensor (padded channels included).  The parity
+# suite replays these masks in the fp64 oracle to separate kernel error from activation-mask flips.
+ACT_TAP = None
+
+
+def _tap_activation(y, act, residual):
+    if ACT_TAP is not None and act in (H.ACT_RELU, H.ACT_LRELU):
+        u = y.detach() if residual is None else y.detach().float() - residual.detach().float()
+        ACT_TAP.append((u > 0).permute(0, 3, 1, 2).cpu())
 
 
 def conv2d(x, weight, bias, prep, *, pad, pad_mode=H.PAD_ZERO, act=H.ACT_NONE, style=None,
            residual=None, demodulate=True, eps=1e-8):
     """``style`` = (w, to_style.weight, to_style.bias) for the modulated conv, else None."""
     w_style, ts_w, ts_b = style if style is not None else (None, None, None)
-    return _ConvFn.apply(x, weight, bias, w_style, ts_w, ts_b, residual, prep, pad, pad_mode, act,
-                         demodulate, eps)
+    y = _ConvFn.apply(x, weight, bias, w_style, ts_w, ts_b, residual, prep, pad, pad_mode, act,
+                      demodulate, eps)
+    _tap_activation(y, act, residual)
+    return y
 
 
 # --------------------------------------------------------------------------- instance norm
@@ -535,7 +626,9 @@ class _InstNormFn(torch.autograd.Function):
 
 
 def instance_norm_act(x, act=H.ACT_NONE, residual=None, eps=1e-5):
-    return _InstNormFn.apply(x, residual, act, eps)
+    y = _InstNormFn.apply(x, residual, act, eps)
+    _tap_activation(y, act, residual)
+    return y
 
 
 # -------------------------------------------------------------------------------- resample

@@ -174,12 +174,19 @@ class _Fn(nn.Module):
         return self.fn(x)
 
 
-def _relu():
-    return _Fn(torch.relu)
+# Test hook (tests/test_hip_parity.py, shared-mask gradient check): when set to a callable
+# ``(kind, tensor, inplace) -> tensor`` it replaces every ReLU / LeakyReLU of the oracle networks, e.g.
+# to replay the activation masks recorded from another run.  None = the plain functions.
+ACT_OVERRIDE = None
+
+
+def _relu(inplace=False):
+    plain = torch.relu_ if inplace else torch.relu
+    return _Fn(lambda t: plain(t) if ACT_OVERRIDE is None else ACT_OVERRIDE("relu", t, inplace))
 
 
 def _lrelu():
-    return _Fn(lambda t: F.leaky_relu(t, 0.2))
+    return _Fn(lambda t: F.leaky_relu(t, 0.2) if ACT_OVERRIDE is None else ACT_OVERRIDE("lrelu", t, False))
 
 
 def _inorm():
@@ -293,7 +300,7 @@ class Generator(nn.Module):
             # nn.ReLU(inplace=True) (builder.py:196): it aliases the map that extract()
             # appended one line earlier, so every non-final Conv2dWeightModulate feature
             # is returned post-ReLU; the final one is returned before the ReLU runs.
-            dec += [Up(), ModConv(f, f // 2, 3, w_dim, 1), _Fn(torch.relu_)]
+            dec += [Up(), ModConv(f, f // 2, 3, w_dim, 1), _relu(inplace=True)]
             f //= 2
         dec += [_rpad(3), EqConv(f, input_nc, 7), _Fn(torch.tanh)]
         self.decoder = nn.ModuleList(dec)

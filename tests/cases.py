@@ -19,7 +19,36 @@ from collections import OrderedDict
 
 import torch
 
-from oracle.detweights import fill_state_dict, image_batch, sym_uniform, unit_uniform
+from oracle import detweights as _dw
+from oracle.detweights import fill_state_dict
+
+_FP64 = {"on": False}
+
+
+def _maybe_double(fn):
+    def wrapped(*a, **k):
+        t = fn(*a, **k)
+        return t.double() if _FP64["on"] else t
+    return wrapped
+
+
+# closed-form fp32 inputs; promoted (exactly) to float64 inside ``fp64_mode``
+image_batch, sym_uniform, unit_uniform = (_maybe_double(f) for f in (_dw.image_batch, _dw.sym_uniform, _dw.unit_uniform))
+
+
+@contextlib.contextmanager
+def fp64_mode():
+    """Run a case in float64: modules are built with double parameters (same closed-form values),
+    inputs are promoted.  Used for noise-free CPU references (shared-mask gradient check,
+    tools/make_fp32_yardstick.py)."""
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    _FP64["on"] = True
+    try:
+        yield
+    finally:
+        _FP64["on"] = False
+        torch.set_default_dtype(prev)
 
 
 def _cpu(t):
@@ -137,7 +166,7 @@ def case_generator(ns, device, *, tag, nc, size, min_latent, n_res, start_filter
     out["gw"] = _cpu(w.grad)
     for name, p in g.named_parameters():
         # biases ahead of InstanceNorm get rounding-noise gradients: skip
-        if name in ("encoder.1.bias", "encoder.4.bias", "encoder.8.bias"):
+        if name in ("encoder.1.bias", "encoder.4.bias", "encoder.8.bias", "encoder.12.bias"):
             continue
         _put(out, f"g/{name}", p.grad)
     return out
@@ -234,8 +263,9 @@ def case_imagebuffer(ns, device, *, tag):
 # ---------------------------------------------------------------------------- step cases
 
 
-def make_config(nc, size, batch):
-    """Stock config.toml values with image_size / image_channels / batch_size overridden."""
+def make_config(nc, size, batch, min_latent=64):
+    """Stock config.toml values with image_size / image_channels / batch_size (and, for the
+    3-downsample case, min_latent_resolution) overridden."""
     return {
         "training": {"batch_size": batch, "random_seed": 42, "training_steps": 150000,
                      "image_buffer_size": 100, "style_mixing_prob": 0.9,
@@ -247,7 +277,7 @@ def make_config(nc, size, batch):
                          "adam_betas": [0.5, 0.99]},
         "ada": {"discriminator_real_acc_target": 0.6,
                 "ada_overfitting_measurement_n_images": 256, "ada_adjustment_size": 5.12e-4},
-        "architecture": {"w_dim": 6, "add_latent_noise": False, "min_latent_resolution": 64,
+        "architecture": {"w_dim": 6, "add_latent_noise": False, "min_latent_resolution": min_latent,
                          "n_resnet_blocks": 7, "mapping_network_layers": 2},
         "data": {"image_size": list(size), "image_channels": nc},
     }
@@ -300,8 +330,8 @@ def _batches(tag, stream, cfg):
         i += 1
 
 
-def case_steps(ns, device, *, tag, nc, size, batch, n_steps=2, seed=1234):
-    cfg = make_config(nc, size, batch)
+def case_steps(ns, device, *, tag, nc, size, batch, n_steps=2, seed=1234, min_latent=64):
+    cfg = make_config(nc, size, batch, min_latent)
     nets, opts = build_step_state(ns, device, cfg, tag)
     prints, marks = _batches(tag, "print", cfg), _batches(tag, "mark", cfg)
     buf = ns.ImageBuffer(cfg["training"]["image_buffer_size"])
@@ -361,6 +391,8 @@ _reg("resblock", case_resblock, dim=8, n=2, h=9, w=10)
 _reg("modresblock", case_modresblock, dim=8, wdim=6, n=2, h=9, w=9)
 _reg("gen32", case_generator, nc=3, size=32, min_latent=8, n_res=3, start_filters=8, n=2)
 _reg("gen64_gray", case_generator, nc=1, size=64, min_latent=64, n_res=7, start_filters=16, n=1)
+# BASELINE config #4's topology (512x512: 3 downsamples, 512-channel latent) at a size the CPU finishes
+_reg("gen64_deep", case_generator, nc=3, size=64, min_latent=8, n_res=3, start_filters=64, n=1)
 _reg("disc32", case_patchnet, kind="D", nc=3, size=32, n=2)
 _reg("disc64", case_patchnet, kind="D", nc=3, size=64, n=1)
 _reg("style32", case_patchnet, kind="S", nc=3, size=32, n=2)
@@ -371,10 +403,53 @@ _reg("adap", case_adap)
 _reg("imagebuffer", case_imagebuffer)
 _reg("steps64", case_steps, nc=1, size=(64, 64), batch=4)        # BASELINE config #1
 _reg("steps256", case_steps, nc=3, size=(256, 256), batch=2)     # north-star shape, B=2
+# config #4's topology through the whole step: 3 downsamples, 512-channel latent at 16x16, Co > 256 tiles
+_reg("steps128", case_steps, nc=3, size=(128, 128), batch=2, min_latent=16)
 
-SLOW_CASES = {"steps256"}
+SLOW_CASES = {"steps256", "steps128"}
 
 
 def run_case(name, ns, device):
     fn, kw = CASES[name]
     return fn(ns, torch.device(device), **kw)
+
+
+def run_case_shared_masks(name, product_namespace, oracle_namespace):
+    """The net-level gradient check without activation-mask noise.
+
+    A forward error eps flips the ReLU / LeakyReLU mask of the ~eps fraction of pre-activations that
+    sit within eps of zero, and every flip is an O(1) change of that element's gradient -- noise that
+    says nothing about the kernels.  Here the HIP path runs first and records the sign mask of every
+    fused activation (ops.ACT_TAP); the oracle then runs in FLOAT64 with those masks REPLAYED in place
+    of its own ReLU / LeakyReLU decisions (oracle.model.ACT_OVERRIDE).  Both sides differentiate the
+    same piecewise-linear function, so what remains is kernel error (times the conditioning of the
+    case).  Returns (product outputs, oracle outputs, flipped mask elements, mask elements)."""
+    import one_to_many_gan_amd.ops as pops
+    import oracle.model as om
+
+    tape = []
+    pops.ACT_TAP = tape
+    try:
+        got = run_case(name, product_namespace, "cuda")
+    finally:
+        pops.ACT_TAP = None
+    masks = iter(tape)
+    count = [0, 0]
+
+    def replay(kind, t, inplace):
+        m = next(masks)[:, : t.shape[1]]
+        assert m.shape == t.shape, (kind, tuple(m.shape), tuple(t.shape))
+        count[0] += int(((t.detach() > 0) != m).sum())
+        count[1] += m.numel()
+        if kind == "relu":
+            return t.mul_(m.to(t.dtype)) if inplace else t * m.to(t.dtype)
+        return torch.where(m, t, 0.2 * t)
+
+    om.ACT_OVERRIDE = replay
+    try:
+        with fp64_mode():
+            want = run_case(name, oracle_namespace, "cpu")
+    finally:
+        om.ACT_OVERRIDE = None
+    assert next(masks, None) is None, "the oracle applied fewer activations than the HIP path recorded"
+    return got, want, count[0], count[1]

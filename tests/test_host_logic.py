@@ -204,3 +204,16 @@ def test_load_config_reads_the_reference_schema(tmp_path):
     (tmp_path / "bad.toml").write_text("[training]\nbatch_size = 4\n")
     with pytest.raises(KeyError):
         load_config(tmp_path / "bad.toml")
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`python bench.py --gpus N` without a launcher starts N ranks itself -- and on a box with fewer
+    GPUs exits non-zero instead of reporting a 1-rank number as the N-GPU one (round-1 defect)."""
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "O2M_SHARE_GPU")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "refusing to report a 64-GPU number" in r.stderr and "{" not in r.stdout

@@ -21,26 +21,35 @@ def test_train_loop_checkpoint_and_resume(tmp_path):
     lines = []
     nets, opts = train.run(cfg, dev, 3, train.synthetic_batches(1, cfg, dev), train.synthetic_batches(2, cfg, dev),
                            log=lines.append)
-    assert any(l.startswith("[2/3]") for l in lines) and any(l.startswith("[3/3]") for l in lines)
+    # the reference's log line (evaluation.py:288-304), also appended to <run>/log (train.py:253-267)
+    assert any(l.startswith("Step: 2/3, D loss: ") for l in lines) and any(l.startswith("Step: 3/3, ") for l in lines)
+    logged = (tmp_path / "t" / "log").read_text().splitlines()
+    assert len(logged) == 2 and logged[1].startswith("Step: 3/3, D loss: ") and logged[1].endswith(", ")
     ck = tmp_path / "t" / "models" / "3.tar"
     assert ck.exists() and (tmp_path / "t" / "models" / "2.tar").exists()
+    # image grids of evaluation.py:122-221
+    for name in ("translation_2.png", "decoding_2.png", "translation_3.png", "decoding_3.png"):
+        assert (tmp_path / "t" / "images" / name).stat().st_size > 10000, name
     blob = torch.load(ck, map_location="cpu", weights_only=True)
-    for key in ("generator_state_dict", "discriminator_state_dict", "mapping_network_state_dict",
-                "style_extractor_state_dict", "generator_optimiser_state_dict", "ada_p", "image_buffer",
-                "image_buffer_size"):
-        assert key in blob, key
-    assert len(blob["image_buffer"]) == 12  # 3 steps x batch 4 generated images pooled
+    from tests.test_boundary_formats import REF_KEYS
+
+    assert list(blob)[: len(REF_KEYS)] == REF_KEYS  # the reference's eleven keys, in its order
+    assert len(blob["image_buffer_images"]) == 12  # 3 steps x batch 4 generated images pooled
+    assert all(t.shape == (1, 1, 64, 64) and t.dtype == torch.float32 for t in blob["image_buffer_images"])
+    assert float(blob["generator_optim_state_dict"]["state"][0]["step"]) == 3.0
     # resume continues from step 3 with identical weights and Adam state
     lines2 = []
     nets2, opts2 = train.run(cfg, dev, 4, train.synthetic_batches(1, cfg, dev), train.synthetic_batches(2, cfg, dev),
                              resume=ck, log=lines2.append)
     assert lines2[0].endswith("at step 3")
     assert float(opts2["G"].step_t) == 4.0
+    # torch's own Adam reads the optimiser entry (reference-side tooling)
     # the oracle's modules load the same checkpoint (reference key layout)
     from oracle import model as om
 
     g = om.Generator(1, 6, (64, 64), 64, 7)
     g.load_state_dict(blob["generator_state_dict"])
+    torch.optim.Adam(g.parameters()).load_state_dict(blob["generator_optim_state_dict"])
 
 
 def test_train_loop_on_image_folders(tmp_path):
@@ -73,5 +82,5 @@ def test_train_loop_on_image_folders(tmp_path):
     assert len(loaders[0]) == 1 and len(loaders[1]) == 1  # drop_last
     lines = []
     train.run(cfg, dev, 2, loaders[0].cycle(), loaders[1].cycle(), log=lines.append)
-    assert any(l.startswith("[2/2]") for l in lines)
+    assert any(l.startswith("Step: 2/2, ") for l in lines)
     assert all("nan" not in l.lower() for l in lines)

@@ -4,6 +4,8 @@ its own ``config.toml`` (same keys), minus the parts that are out of scope (FID/
 matplotlib grids, the author's image folders).
 
   python train.py config.toml [--steps N] [--synthetic] [--resume ckpt.tar] [--precision bf16|fp32]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 train.py config.toml
+      (data parallel: one process per GPU, RCCL gradient all-reduce, batch_size per GPU)
 
 Data: ``--synthetic`` (default when the configured directories do not exist) draws
 uniform [-1, 1) images resident in HBM, as bench.py does.  Real data: image folders through the
@@ -17,13 +19,15 @@ import argparse
 import itertools
 import random
 import sys
+import os
 import time
+from pathlib import Path
 
 import numpy as np
 import torch
 
 import one_to_many_gan_amd as o2m
-from one_to_many_gan_amd.core.evaluation import Logger, load_checkpoint, model_checkpoint
+from one_to_many_gan_amd.core.evaluation import Logger, image_checkpoint, load_checkpoint, model_checkpoint
 from one_to_many_gan_amd.core.training import ImageBuffer, discriminator_step, generator_step
 from one_to_many_gan_amd.data.config import load_config
 from one_to_many_gan_amd.model.builder import Discriminator, Generator, MappingNetwork, StyleExtractor
@@ -61,7 +65,16 @@ def build(config, device):
     return nets, opts
 
 
-def run(config, device, steps, shoeprint_iter, shoemark_iter, resume=None, log=print):
+def run(config, device, steps, shoeprint_iter, shoemark_iter, resume=None, log=print, data_parallel=False,
+        image_grids=True):
+    """The loop of the reference's train.py:171-319.  ``data_parallel``: torch.distributed is
+    initialised (one rank per GPU); gradients, the KL moments and the ADA confidence are reduced
+    over ranks (one_to_many_gan_amd/dist.py) and only rank 0 logs and writes checkpoints."""
+    if device.type == "cuda":
+        # the launchers enqueue on the CURRENT stream of the tensors' device; make that device the
+        # process's current one as well so allocations and events follow (train.py:61-65)
+        torch.cuda.set_device(device)
+    o2m.ops.set_deterministic(bool(config["training"].get("deterministic_cuda_kernels", False)))
     nets, opts = build(config, device)
     image_buffer = ImageBuffer(config["training"]["image_buffer_size"])
     ada = o2m.AdaptiveDiscriminatorAugmentation(**o2m.REFERENCE_ADA_SWITCHES).to(device)  # train.py:175-188
@@ -69,6 +82,19 @@ def run(config, device, steps, shoeprint_iter, shoemark_iter, resume=None, log=p
                  ada_adjustment_size=config["ada"]["ada_adjustment_size"],
                  batch_size=config["training"]["batch_size"],
                  discriminator_overfitting_target=config["ada"]["discriminator_real_acc_target"])
+    kl_hook, rank = None, 0
+    if data_parallel:
+        import torch.distributed as dist
+
+        from one_to_many_gan_amd import dist as o2m_dist
+
+        rank = dist.get_rank()
+        o2m_dist.broadcast_parameters(opts.values())
+        for o in opts.values():
+            o2m_dist.BucketReducer(o)
+        kl_hook = o2m_dist.make_kl_moment_hook()
+        o2m_dist.sync_ada_p(ada_p)
+        torch.manual_seed(config["training"]["random_seed"] + 1 + rank)  # z / theta / h differ per rank
     first = 0
     if resume:
         first = load_checkpoint(resume, device, nets["G"], nets["D"], nets["M"], nets["S"], opts["G"], opts["D"],
@@ -89,17 +115,34 @@ def run(config, device, steps, shoeprint_iter, shoemark_iter, resume=None, log=p
         logger.log_disc_fake_accs.append(fake_acc)
         g_loss, (gan, rec, idt, kl, path, style) = generator_step(
             config, device, nets["G"], nets["D"], nets["M"], nets["S"], opts["G"], opts["M"], opts["S"],
-            shoeprint_iter, shoemark_iter, ada)
+            shoeprint_iter, shoemark_iter, ada, kl_moment_hook=kl_hook)
         for name, v in (("total_gen", g_loss), ("gan", gan), ("rec", rec), ("idt", idt), ("kl", kl),
                         ("path", path), ("style", style)):
             getattr(logger, f"log_{name}_losses").append(v)
+        if rank != 0:
+            continue
         if (step + 1) % ev["log_interval"] == 0 or step + 1 == steps:
-            dt = time.perf_counter() - t0
-            log(logger.print(step + 1) + f" | {dt:.1f}s")
+            line = logger.print(step + 1)  # the reference's line, also appended to <run>/log (train.py:253-267)
+            log(line)
+            run_dir = Path(config["training"]["checkpoint_directory"]) / config["training"]["training_run"]
+            run_dir.mkdir(parents=True, exist_ok=True)
+            with (run_dir / "log").open("a") as f:
+                f.write(line + "\n")
+            log(f"elapsed {time.perf_counter() - t0:.1f}s")
         if (step + 1) % ev["checkpoint_interval"] == 0 or step + 1 == steps:
+            # train.py:269-315 without val_checkpoint (FID / KID need network-fetched weights)
+            for k in ("G", "M", "S"):
+                nets[k].eval()
+            if image_grids:
+                with torch.no_grad():
+                    grids = image_checkpoint(step, config, device, shoeprint_iter, shoemark_iter, nets["M"],
+                                             nets["G"], nets["S"])
+                log(f"image grids {grids[0]} {grids[1]}")
             path_ = model_checkpoint(step, config, nets["G"], nets["D"], nets["M"], nets["S"], opts["G"], opts["D"],
                                      opts["M"], opts["S"], ada_p, image_buffer)
             log(f"checkpoint {path_}")
+            for k in ("G", "M", "S"):
+                nets[k].train()
     return nets, opts
 
 
@@ -114,24 +157,38 @@ def main(argv=None):
     config = load_config(args.config)
     if not torch.cuda.is_available():
         sys.exit("train.py drives the MI355X hot path: no GPU visible (there is no CPU fallback)")
-    device = torch.device(f"cuda:{config['training']['gpu_number']}")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:  # one rank per GPU; gpu_number names the single-process device only
+        import torch.distributed as dist
+
+        device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        torch.cuda.set_device(device)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(os.environ.get("O2M_DIST_BACKEND", "nccl"),
+                                **({"device_id": device} if os.environ.get("O2M_DIST_BACKEND", "nccl") == "nccl" else {}))
+    else:
+        device = torch.device(f"cuda:{config['training']['gpu_number']}")
+        torch.cuda.set_device(device)
     o2m.set_precision(args.precision)
     have_data = config["data"]["shoeprint_data_dir"].exists() and config["data"]["shoemark_data_dir"].exists()
     steps = args.steps if args.steps is not None else config["training"]["training_steps"]
+    rank = int(os.environ.get("RANK", "0"))
     if args.synthetic or not have_data:
-        prints, marks = synthetic_batches(1000, config, device), synthetic_batches(2000, config, device)
+        prints, marks = synthetic_batches(1000 + rank, config, device), synthetic_batches(2000 + rank, config, device)
     else:
         # reference train.py:118-169 with the images resident in HBM (data/datasets.py)
         from one_to_many_gan_amd.data import datasets as D
 
         tf = D.Compose([D.Resize(tuple(config["data"]["image_size"])), D.ToTensor(), D.Normalize((0.5,), (0.5,))])
-        g = torch.Generator().manual_seed(config["training"]["random_seed"])
+        g = torch.Generator().manual_seed(config["training"]["random_seed"] + rank)
         loaders = []
         for key in ("shoeprint_data_dir", "shoemark_data_dir"):
             pool = D.DeviceImagePool(D.ShoeDataset(config["data"][key], mode="train", transform=tf), device)
             loaders.append(D.DeviceLoader(pool, config["training"]["batch_size"], generator=g))
         prints, marks = loaders[0].cycle(), loaders[1].cycle()
-    run(config, device, steps, prints, marks, resume=args.resume)
+    run(config, device, steps, prints, marks, resume=args.resume, data_parallel=world > 1)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
