@@ -79,9 +79,21 @@ typedef struct {
   int32_t stride;         /* 0 or 1: stride 1; s > 1: Ho = (H + 2*pad - KH)/s + 1.  Used by the host
                              for the space-to-depth form of the N = 3 image conv (a 7x7 stride-1
                              conv with 3 outputs = a 10x10 stride-4 conv with 48 outputs) */
-  int32_t reserved[3];
+  int32_t reserved[1];
+  float* stats;           /* NULL, or InstanceNorm partial sums emitted by the epilogue:
+                             stats[(m / R) * Co * 2 + o * 2 + {0, 1}] = sum / sum of squares of y[., o] (fp32,
+                             before the rounding to `dtype`) over the R consecutive output pixels m .. m+R-1,
+                             R = o2m_conv2d_stats_rows(d).  Requires R > 0, act NONE, no residual.  Every
+                             (m / R, o) entry is written by exactly one workgroup (deterministic, no atomics);
+                             o2m_instnorm_finalize turns the Ho*Wo/R partials of a sample into mean / rstd, so
+                             the separate statistics pass over y (nn.InstanceNorm2d, builder.py:164,172,...;
+                             blocks.py:23,27) disappears. */
 } o2m_conv_desc;
 int o2m_conv2d_fwd(const o2m_conv_desc* d, void* stream);
+/* Rows per InstanceNorm partial for this problem (the tile configuration o2m_conv2d_fwd would select),
+ * or 0 when the epilogue cannot emit them (Ho*Wo not a multiple of the tile's row block: the odd-sized
+ * discriminator maps -- the caller then runs o2m_instnorm_stats).  d->stats itself is not read. */
+int32_t o2m_conv2d_stats_rows(const o2m_conv_desc* d);
 
 /* Kernel-side forms of one equalised-LR filter (layers.py:12-24: W*c is recomputed on every
  * forward).  w is the parameter, fp32 [Co][Ci][KK] (KK = KH*KW).  Written:
@@ -200,6 +212,10 @@ int o2m_fold_scale_dot(const void* gpad, const void* x, const float* scale, void
  * `partial` is caller workspace of o2m_instnorm_ws_floats(B,P,C) floats.
  */
 size_t o2m_instnorm_ws_floats(int32_t B, int32_t P, int32_t C);
+/* Second stage alone: partial [B][nchunks][C][2] (from o2m_conv2d_fwd's epilogue, nchunks = P / R) ->
+ * mean_rstd [B][C][2]. */
+int o2m_instnorm_finalize(const float* partial, float* mean_rstd, int32_t B, int32_t P, int32_t C,
+                          int32_t nchunks, float eps, void* stream);
 int o2m_instnorm_stats(const void* x, float* partial, float* mean_rstd, int32_t B, int32_t P,
                        int32_t C, float eps, int32_t dtype, void* stream);
 int o2m_instnorm_apply(const void* x, const float* mean_rstd, const void* residual, void* y,

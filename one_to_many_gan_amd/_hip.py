@@ -32,7 +32,7 @@ BF16, F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 PAD_ZERO, PAD_REFLECT = 0, 1
 RED_L1, RED_SQ, RED_MOM = 0, 1, 2
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -42,7 +42,7 @@ class ConvDesc(C.Structure):
                 ("bias", _vp), ("residual", _vp),
                 ("B", _i32), ("H", _i32), ("W", _i32), ("Ci", _i32), ("Co", _i32), ("KH", _i32),
                 ("KW", _i32), ("pad", _i32), ("pad_mode", _i32), ("act", _i32), ("dtype", _i32),
-                ("w_batch_stride", _i32), ("stride", _i32), ("reserved", _i32 * 3)]
+                ("w_batch_stride", _i32), ("stride", _i32), ("reserved", _i32 * 1), ("stats", _vp)]
 
 
 class WgradDesc(C.Structure):
@@ -56,6 +56,8 @@ class WgradDesc(C.Structure):
 SIGNATURES = {
     "o2m_abi_version": (_i32, []),
     "o2m_conv2d_fwd": (_i32, [C.POINTER(ConvDesc), _vp]),
+    "o2m_conv2d_stats_rows": (_i32, [C.POINTER(ConvDesc)]),
+    "o2m_instnorm_finalize": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),
     "o2m_conv2d_wgrad": (_i32, [C.POINTER(WgradDesc), _vp]),
     "o2m_wgrad_finalize": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
     "o2m_style_fwd": (_i32, [_vp] * 6 + [_i32] * 5 + [_f32, _f32, _vp]),
@@ -85,21 +87,24 @@ SIGNATURES = {
 }
 
 _lib = None
+P8_ENABLED = os.environ.get("O2M_IGEMM_P8", "1") != "0"  # mirrors the switch in csrc/conv_igemm.hip
 
 # bench.py sets this to a list to time every MFMA conv launch with a HIP-event pair on the
 # launch stream: entries are (kernel_name, algorithmic_flops, start_event, end_event).
 PROFILE = None
 
 
-def _igemm_name(dt, co, scaled, m=1 << 30, k=1 << 30):
+def _igemm_name(dt, co, scaled, m=1 << 30, k=1 << 30, ci=64):
     """Mirrors launch_dtype() in csrc/conv_igemm.hip, so the labels map one-to-one onto the
-    template instantiations rocprofv3 reports."""
+    kernels rocprofv3 reports."""
     t = "bf16" if dt == torch.bfloat16 else "f32x3"
 
     def tiles(bm, bn):
         return -(-m // bm) * -(-co // bn)
 
     if co > 128:
+        if tiles(256, 256) >= 256 and dt == torch.bfloat16 and not scaled and ci % 64 == 0 and P8_ENABLED:
+            return "conv_igemm_p8<bf16,256x256>"
         tile = "256x256" if tiles(256, 256) >= 256 else "128x128"
     elif co > 64:
         if k <= 1152 and tiles(256, 64) >= 512:
@@ -206,14 +211,21 @@ def check(err: int, what: str):
 
 
 def conv2d_fwd(x, w, y, *, in_scale=None, out_scale=None, bias=None, residual=None, pad, pad_mode, act,
-               per_sample_w=False, stride=1):
+               per_sample_w=False, stride=1, stats=None):
+    """``stats``: fp32 workspace for the InstanceNorm partial sums of y (see o2m_conv_desc.stats)."""
     if PROFILE is None:
-        return ops().conv2d_fwd(x, w, y, in_scale, out_scale, bias, residual, pad, pad_mode, act, per_sample_w, stride)
+        return ops().conv2d_fwd(x, w, y, in_scale, out_scale, bias, residual, pad, pad_mode, act, per_sample_w, stride,
+                                stats)
     Co, KH, KW, Ci = w.shape[-4:]
     m = y.shape[0] * y.shape[1] * y.shape[2]
-    _timed(_igemm_name(x.dtype, Co, in_scale is not None, m, KH * KW * Ci), 2.0 * m * Co * KH * KW * Ci, x,
+    _timed(_igemm_name(x.dtype, Co, in_scale is not None, m, KH * KW * Ci, Ci), 2.0 * m * Co * KH * KW * Ci, x,
            lambda: ops().conv2d_fwd(x, w, y, in_scale, out_scale, bias, residual, pad, pad_mode, act, per_sample_w,
-                                    stride))
+                                    stride, stats))
+
+
+def conv2d_stats_rows(x, w, y, *, pad, stride=1):
+    """Rows per InstanceNorm partial the epilogue of this conv would emit (0: not available)."""
+    return ops().conv2d_stats_rows(x, w, y, pad, stride)
 
 
 def conv2d_wgrad(x, gy, dw, *, in_scale=None, gy_scale=None, pad, pad_mode, splits=0, more=(), stride=1):
@@ -263,6 +275,11 @@ def instnorm_ws_floats(B, P, Cn):
 
 def instnorm_stats(x, partial, mean_rstd, eps):
     ops().instnorm_stats(x, partial, mean_rstd, eps)
+
+
+def instnorm_finalize(partial, mean_rstd, P, nchunks, eps):
+    """Second stage of the statistics alone: conv-epilogue partials [B][nchunks][C][2] -> mean / rstd."""
+    ops().instnorm_finalize(partial, mean_rstd, P, nchunks, eps)
 
 
 def instnorm_apply(x, mean_rstd, residual, y, act):

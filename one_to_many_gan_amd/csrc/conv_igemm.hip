@@ -99,6 +99,28 @@ __device__ __forceinline__ void stg_to_lds(const Stg<T>& s, const f32x4 (&sc)[2]
   }
 }
 
+// InstanceNorm partial sums from the epilogue (o2m_conv_desc.stats).  Every thread of the read-out
+// loop keeps ONE 8-channel vector (NT % (BN/8) == 0) and walks rows, so it sums its rows in
+// registers; the NT / VPR threads that share a vector are then added through LDS (the staged tile
+// is dead by then) and one thread per (channel, statistic) writes the partial: no atomics, a fixed
+// summation order.
+template <int NT, int VPR>
+__device__ __forceinline__ void stats_block_reduce(const float (&st)[16], float* red, float* __restrict__ stats,
+                                                   long part, int n0, int Co, int tid) {
+  __syncthreads();  // every thread has finished reading the staged tile
+#pragma unroll
+  for (int q = 0; q < 16; ++q) red[q * NT + tid] = st[q];
+  __syncthreads();
+  if (tid < VPR * 16) {
+    const int c8 = tid % VPR, q = tid / VPR;
+    float s = 0.f;
+#pragma unroll 4
+    for (int k = 0; k < NT / VPR; ++k) s += red[q * NT + c8 + VPR * k];
+    const int n = n0 + c8 * 8 + (q & 7);
+    if (n < Co) stats[((size_t)part * Co + n) * 2 + (q >> 3)] = s;
+  }
+}
+
 // 16 zero bytes in global memory: the LDS-DMA source of every padding / out-of-problem slot
 __device__ __attribute__((aligned(16))) unsigned int o2m_zero16[4] = {0u, 0u, 0u, 0u};
 
@@ -440,6 +462,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
     }
     __syncthreads();
     const int mbase = m0 + pass * WM;
+    float st[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) st[q] = 0.f;
 #pragma unroll 1
     for (int v = tid; v < WM * VPR; v += NT) {
       const int row = v / VPR, c8 = v - row * VPR;
@@ -459,6 +484,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
 #pragma unroll
         for (int q = 0; q < 4; ++q) { o[q] += b0[q]; o[4 + q] += b1[q]; }
       }
+      if (d.stats) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { st[q] += o[q]; st[8 + q] += o[q] * o[q]; }
+      }
       if (act != O2M_ACT_NONE) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) o[q] = act_fwd(o[q], act);
@@ -471,6 +500,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
         for (int q = 0; q < 8; ++q) o[q] += rv[q];
       }
       store8(Y + off, o);
+    }
+    if (d.stats) {
+      if constexpr (NT % VPR == 0 && VPR * 16 <= NT)
+        stats_block_reduce<NT, VPR>(st, csm, d.stats, (long)(mbase / WM), n0, Co, tid);
     }
     if (pass + 1 < WAVES_M) __syncthreads();
   }
@@ -490,6 +523,352 @@ long tiles_for(const o2m_conv_desc& d) {
   const int Ho = (d.H + 2 * d.pad - d.KH) / S + 1, Wo = (d.W + 2 * d.pad - d.KW) / S + 1;
   const long M = (long)d.B * Ho * Wo;
   return ((M + BM - 1) / BM) * ((d.Co + BN - 1) / BN);
+}
+
+// =============================================================================================
+// Phase-pipelined variant ("p8") of the 256 x 256 x 64 tile: bf16, Ci % 64 == 0, no in_scale,
+// stride 1.  The symmetric kernel above ends every K-stage in `s_waitcnt vmcnt(0)` + barrier with
+// all eight waves filling, then all eight multiplying: the matrix pipe idles while the fills are
+// issued and the waves park at the drain (profiles/r01_k: 39 % of wave cycles waiting).  Here
+//
+//  * 8 waves = 2 (M) x 4 (N), wave tile 128 x 64, v_mfma_f32_16x16x32_bf16 (128 accumulator VGPRs);
+//  * a K-tile is computed in FOUR phases, one 64 x 32 quadrant of the wave tile each:
+//      p1 A0 x B0, p2 A0 x B1, p3 A1 x B1, p4 A1 x B0   (A0/A1 = the wave's pixel rows 0-63 / 64-127,
+//      B0/B1 = its filter rows 0-31 / 32-63), so a phase reads at most one new operand half from LDS
+//      (8 or 4 ds_read_b128) and issues 16 MFMAs;
+//  * a phase is   { LDS reads for its MFMAs ; issue ONE region of LDS-DMA fills ; s_waitcnt vmcnt(8) }
+//                 s_barrier  { 16 MFMAs }  s_barrier
+//    and the two wave rows run ONE BARRIER APART (the M = 1 row does an extra s_barrier up front): on
+//    every SIMD one wave multiplies while its partner reads fragments and issues fills, so the matrix
+//    pipe alternates between the two instead of idling;
+//  * the fills are cut into four REGIONS per K-tile by the phase that reads them (A0: tile rows
+//    0-63 + 128-191, A1: the other A rows, B0 / B1 likewise over the four 64-row filter blocks), each
+//    16 fills = 2 per wave.  Region X needed by phase n is issued in phase n - 5, so four regions
+//    (8 fills per wave) stay in flight ACROSS the barriers and the only wait in the loop is the counted
+//    `vmcnt(8)` = "everything but the four youngest regions has landed"; nothing ever drains to 0.
+//    Two 64 KB LDS buffers (K-tile parity); a region is overwritten >= 3 phases after its last read.
+//  * past the end of the reduction the fills are issued with out-of-range offsets (hardware zero
+//    fill, no memory traffic) so the instruction counts behind vmcnt(8) stay uniform.
+//
+// Synchronisation rules used (MI355X guide, "Read a staged buffer one phase AFTER the wait that
+// retires it"): a region is read only after every wave has passed a vmcnt that covers its fills and
+// then a barrier; it is refilled only after every reader has passed the lgkmcnt of its last read and
+// then a barrier.  Per phase n the wait leaves regions n+2 .. n+5 in flight, i.e. guarantees n+1.
+// =============================================================================================
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+// Diagnostic build only (-DO2M_P8_STAMPS, tools/stamp_conv.py): s_memtime stamps around the segments of
+// a phase, summed per wave in scalar registers; never compiled into libo2m_hip.so.
+#ifdef O2M_P8_STAMPS
+__device__ unsigned long long o2m_p8_stamps[2][8];
+#define P8_STAMP(i)                                                                        \
+  do {                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                     \
+    unsigned long long t_;                                                                 \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");             \
+    __builtin_amdgcn_sched_barrier(0);                                                     \
+    st_sum[i] += t_ - st_last;                                                             \
+    st_last = t_;                                                                          \
+  } while (0)
+#else
+#define P8_STAMP(i) do {} while (0)
+#endif
+
+__global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_desc d) {
+  using T = unsigned short;
+  constexpr int BM = 256, BN = 256, NT = 512;
+  constexpr int OPB = 32768;   // one operand of one K-tile: 256 rows x 128 B
+  constexpr int BUFB = 65536;  // A + B
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int H = d.H, W = d.W, Ci = d.Ci, Co = d.Co, KH = d.KH, KW = d.KW, pad = d.pad;
+  const int Ho = H + 2 * pad - KH + 1, Wo = W + 2 * pad - KW + 1;
+  const int HoWo = Ho * Wo;
+  const int M = d.B * HoWo;
+  const int K = KH * KW * Ci;
+  const int nk = K / BK;
+  const bool reflect = d.pad_mode == O2M_PAD_REFLECT;
+
+  const int tiles_n = (Co + BN - 1) / BN;
+  const int tile = xcd_tile_order(blockIdx.x, gridDim.x);
+  const int m0 = (tile / tiles_n) * BM;
+  const int n0 = (tile % tiles_n) * BN;
+  const int b_first = m0 / HoWo;
+  const bool b_uniform = (min(m0 + BM, M) - 1) / HoWo == b_first;
+  const rsrc_t xr = make_rsrc(d.x, (unsigned)((size_t)d.B * H * W * Ci * 2));
+  const rsrc_t wr = make_rsrc(static_cast<const char*>(d.w) + (size_t)b_first * d.w_batch_stride * 2,
+                              (unsigned)((size_t)Co * K * 2));
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int wrow = wave >> 2, wcol = wave & 3;
+  typedef __attribute__((address_space(3))) void lds_void;
+
+  // ---- fills: slot j = 2 * region + (0 | 1); the wave owns entries 2w, 2w+1 of each region's list ----
+  // A regions: A0 = 8-row groups {0..7, 16..23}, A1 = {8..15, 24..31};  B: B0 = {8c + 0..3}, B1 = {8c + 4..7}
+  auto a_group = [&](int j) { const int i = 2 * wave + (j & 1); return (i < 8 ? i : i + 8) + 8 * (j >> 1); };
+  auto b_group = [&](int j) { const int i = 2 * wave + (j & 1); return 8 * (i >> 2) + 4 * (j >> 1) + (i & 3); };
+  // lane l of the fill of group q owns linear 16-B slot 64 q + l = (row, chunk) under tile_off's swizzle
+  auto slot_row = [&](int q) { const int pr = 4 * q + (lane >> 4); return 2 * pr + (((lane & 15) ^ (pr & 15)) >> 3); };
+  auto slot_chk = [&](int q) { const int pr = 4 * q + (lane >> 4); return ((lane & 15) ^ (pr & 15)) & 7; };
+
+  int pix[4], ryx[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int m = m0 + slot_row(a_group(j));
+    if (m < M) {
+      const int b = m / HoWo, rem = m - b * HoWo;
+      const int oy = rem / Wo, ox = rem - oy * Wo;
+      pix[j] = (b * H + oy) * W + ox;
+      ryx[j] = (oy << 16) | ox;
+    } else {
+      pix[j] = -1;
+      ryx[j] = 0;
+    }
+  }
+  unsigned dwoff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int q = b_group(j);
+    const int n = n0 + slot_row(q);
+    dwoff[j] = n < Co ? (unsigned)(n * K + slot_chk(q) * 8) * 2u : OOB_OFF;
+  }
+  unsigned aoff[4];
+  // per-region stream state (wave-uniform): next K-tile's tap (ky, kx), channel base, LDS buffer
+  int a_ky[2] = {0, 0}, a_kx[2] = {0, 0}, a_cb[2] = {0, 0}, a_buf[2] = {0, 0};
+  int b_kt[2] = {0, 0};
+
+  auto issue_a = [&](int r) {
+    if (a_cb[r] == 0) {  // first K-tile of a tap: gather offsets of this region's two fills
+      const int dy = a_ky[r] - pad, dx = a_kx[r] - pad;
+      const bool live = a_ky[r] < KH;  // past the reduction: zero fills, no traffic
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int j = 2 * r + jj;
+        const int oy = ryx[j] >> 16, ox = ryx[j] & 0xffff;
+        int iy = oy + dy, ix = ox + dx;
+        bool ok = live && pix[j] >= 0;
+        if (reflect) {
+          iy = iy < 0 ? -iy : (iy >= H ? 2 * H - 2 - iy : iy);
+          ix = ix < 0 ? -ix : (ix >= W ? 2 * W - 2 - ix : ix);
+        } else {
+          ok = ok && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        }
+        aoff[j] = ok ? (unsigned)((pix[j] + (iy - oy) * W + (ix - ox)) * Ci + slot_chk(a_group(j)) * 8) * 2u : OOB_OFF;
+      }
+    }
+    char* dst = smem + a_buf[r] * BUFB;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int j = 2 * r + jj;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void*)(dst + a_group(j) * 1024), 16, (int)aoff[j], a_cb[r] * 2, 0, 0);
+    }
+    a_buf[r] ^= 1;
+    a_cb[r] += BK;
+    if (a_cb[r] == Ci) {
+      a_cb[r] = 0;
+      if (++a_kx[r] == KW) { a_kx[r] = 0; ++a_ky[r]; }
+    }
+  };
+  auto issue_b = [&](int r) {
+    const bool live = b_kt[r] < nk;
+    char* dst = smem + (b_kt[r] & 1) * BUFB + OPB;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int j = 2 * r + jj;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void*)(dst + b_group(j) * 1024), 16,
+                                               (int)(live ? dwoff[j] : OOB_OFF), b_kt[r] * (BK * 2), 0, 0);
+    }
+    ++b_kt[r];
+  };
+
+  // ---- fragments ------------------------------------------------------------------------------------
+  // 16x16x32: lane l holds row l & 15, reduction elements 8 (l >> 4) + 32 ks .. +7 = chunk (l >> 4) + 4 ks.
+  // tile_off(R0 + 16 i + r, c + 4 ks) = (tile_off(R0 + r, c) ^ ((i & 1) << 7 | ks << 6)) + i * 2048  for R0 % 32 == 0
+  const int fa0 = tile_off(128 * wrow + (lane & 15), lane >> 4);
+  const int fb0 = tile_off(64 * wcol + (lane & 15), lane >> 4) + OPB;
+  bf16x8 af[4][2], b0f[2][2], b1f[2][2];
+  auto read_a = [&](int buf, int mh) {
+    const char* base = smem + buf * BUFB + mh * (64 * 128);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        af[i][ks] = *reinterpret_cast<const bf16x8*>(base + ((fa0 ^ (((i & 1) << 7) | (ks << 6))) + i * 2048));
+  };
+  auto read_b = [&](bf16x8 (&bf)[2][2], int buf, int nh) {
+    const char* base = smem + buf * BUFB + nh * (32 * 128);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        bf[j][ks] = *reinterpret_cast<const bf16x8*>(base + ((fb0 ^ (((j & 1) << 7) | (ks << 6))) + j * 2048));
+  };
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  auto multiply = [&](const bf16x8 (&bf)[2][2], int mh, int nh) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[mh * 4 + i][nh * 2 + j] =
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][ks], bf[j][ks], acc[mh * 4 + i][nh * 2 + j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+#ifdef O2M_P8_STAMPS
+  unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0;
+#endif
+  // stamp slots: 0 reads + fill issue, 1 vmcnt wait, 2 barrier before the MFMAs, 3 MFMAs, 4 closing barrier
+#define P8_WAIT_AND_SYNC()                                  \
+  do {                                                      \
+    P8_STAMP(0);                                            \
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        \
+    P8_STAMP(1);                                            \
+    __builtin_amdgcn_s_barrier();                           \
+    P8_STAMP(2);                                            \
+  } while (0)
+#define P8_CLOSE()                                          \
+  do {                                                      \
+    P8_STAMP(3);                                            \
+    __builtin_amdgcn_s_barrier();                           \
+    P8_STAMP(4);                                            \
+  } while (0)
+
+  // ---- prologue: regions needed by phases -1 .. 4 -------------------------------------------------------
+  issue_b(0);  // B0(0)
+  issue_a(0);  // A0(0)
+  issue_b(1);  // B1(0)
+  issue_a(1);  // A1(0)
+  issue_b(0);  // B0(1)
+  issue_a(0);  // A0(1)
+  P8_WAIT_AND_SYNC();                           // B0(0), A0(0) have landed for every wave
+  if (wrow == 1) __builtin_amdgcn_s_barrier();  // this wave row runs one barrier behind the other
+  read_b(b0f, 0, 0);
+#ifdef O2M_P8_STAMPS
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
+#endif
+
+  for (int t = 0; t < nk; ++t) {
+    const int cur = t & 1;
+    // p1: A0 x B0
+    read_a(cur, 0);
+    issue_b(1);  // B1(t+1)
+    P8_WAIT_AND_SYNC();
+    multiply(b0f, 0, 0);
+    P8_CLOSE();
+    // p2: A0 x B1
+    read_b(b1f, cur, 1);
+    issue_a(1);  // A1(t+1)
+    P8_WAIT_AND_SYNC();
+    multiply(b1f, 0, 1);
+    P8_CLOSE();
+    // p3: A1 x B1
+    read_a(cur, 1);
+    issue_b(0);  // B0(t+2)
+    P8_WAIT_AND_SYNC();
+    multiply(b1f, 1, 1);
+    P8_CLOSE();
+    // p4: A1 x B0, then the next K-tile's B0 fragments (landed: waited for at the end of p3)
+    issue_a(0);  // A0(t+2)
+    P8_WAIT_AND_SYNC();
+    multiply(b0f, 1, 0);
+    read_b(b0f, cur ^ 1, 0);
+    P8_CLOSE();
+  }
+#undef P8_WAIT_AND_SYNC
+#undef P8_CLOSE
+#ifdef O2M_P8_STAMPS
+  if (blockIdx.x == 7 && (wave == 0 || wave == 4) && lane == 0) {
+    for (int i = 0; i < 8; ++i) o2m_p8_stamps[wave >> 2][i] = st_sum[i];
+  }
+#endif
+  if (wrow == 0) __builtin_amdgcn_s_barrier();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the zero fills issued past the end of the reduction
+  __syncthreads();
+
+  // ---- epilogue: fp32 tile through LDS, whole channel vectors out (as in conv_igemm_kernel) -------------
+  constexpr int CSTR = BN + 4;
+  float* csm = reinterpret_cast<float*>(smem);
+  T* __restrict__ Y = static_cast<T*>(d.y);
+  const T* __restrict__ R = static_cast<const T*>(d.residual);
+  constexpr int VPR = BN / 8;
+  const int act = d.act;
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass == wrow) {
+      // C/D of 16x16x32: column (channel) = lane & 15, row (pixel) = 4 (lane >> 4) + register
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            csm[(i * 16 + 4 * (lane >> 4) + r) * CSTR + wcol * 64 + j * 16 + (lane & 15)] = acc[i][j][r];
+    }
+    __syncthreads();
+    const int mbase = m0 + pass * 128;
+    float st[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) st[q] = 0.f;
+#pragma unroll 1
+    for (int v = tid; v < 128 * VPR; v += NT) {
+      const int row = v / VPR, c8 = v - row * VPR;
+      const int m = mbase + row, n = n0 + c8 * 8;
+      if (m >= M || n >= Co) continue;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(csm + row * CSTR + c8 * 8);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(csm + row * CSTR + c8 * 8 + 4);
+      float o[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+      if (d.out_scale) {
+        const float* sp = d.out_scale + (size_t)(b_uniform ? b_first : m / HoWo) * Co + n;
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { o[q] *= s0[q]; o[4 + q] *= s1[q]; }
+      }
+      if (d.bias) {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(d.bias + n), b1 = *reinterpret_cast<const f32x4*>(d.bias + n + 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { o[q] += b0[q]; o[4 + q] += b1[q]; }
+      }
+      if (d.stats) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { st[q] += o[q]; st[8 + q] += o[q] * o[q]; }
+      }
+      if (act != O2M_ACT_NONE) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] = act_fwd(o[q], act);
+      }
+      const size_t off = (size_t)m * Co + n;
+      if (R) {
+        float rv[8];
+        load8(R + off, rv);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] += rv[q];
+      }
+      store8(Y + off, o);
+    }
+    if (d.stats) stats_block_reduce<NT, VPR>(st, csm, d.stats, (long)(mbase / 128), n0, Co, tid);
+    if (pass == 0) __syncthreads();
+  }
+}
+
+int launch_p8(const o2m_conv_desc& d, hipStream_t s) {
+  constexpr int lds_main = 2 * 65536, lds_epi = 128 * (256 + 4) * 4;
+  constexpr int lds = lds_main > lds_epi ? lds_main : lds_epi;
+  const long tiles = tiles_for<256, 256>(d);
+  if (tiles <= 0 || tiles > 0x7fffffffL) return O2M_ERR_BAD_ARG;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_p8_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipLaunchKernelGGL(conv_igemm_p8_kernel, dim3((unsigned)tiles), dim3(512), lds, s, d);
+  O2M_LAUNCH_CHECK();
+  return 0;
 }
 
 // =============================================================================================
@@ -799,6 +1178,12 @@ int launch_dtype(const o2m_conv_desc& d, hipStream_t s) {
   // big 8-wave tiles when they still give every CU a block; otherwise the 4-wave 128-wide
   // tiles (small-M layers of the discriminator) so the chip stays filled
   if (d.Co > 128) {
+    if constexpr (sizeof(T) == 2) {
+      // O2M_IGEMM_P8=0: the symmetric two-stage kernel instead of the phase-pipelined one (A/B runs)
+      static const int p8 = [] { const char* e = getenv("O2M_IGEMM_P8"); return e ? atoi(e) : 1; }();
+      if (p8 && !d.in_scale && d.stride <= 1 && d.Ci % BK == 0 && tiles_for<256, 256>(d) >= kFillBlocks)
+        return launch_p8(d, s);
+    }
     if (tiles_for<256, 256>(d) >= kFillBlocks) return launch_cfg<T, 256, 256, 2, 4>(d, s);
     return launch_cfg<T, 128, 128, 2, 2>(d, s);
   }
@@ -819,6 +1204,32 @@ int launch_dtype(const o2m_conv_desc& d, hipStream_t s) {
 
 }  // namespace
 
+// rows per InstanceNorm partial = the row block one epilogue pass of the selected configuration covers
+// (mirrors launch_dtype below)
+static int stats_rows_for(const o2m_conv_desc& d) {
+  if (d.stride > 1 || d.in_scale) return 0;
+  if (d.Co > 128) {
+    if (tiles_for<256, 256>(d) >= kFillBlocks) return 128;  // p8 and the symmetric 256x256 kernel alike
+    return 64;                                               // 128x128, 2x2 waves
+  }
+  return 64;  // 256x64 / 256x128 (4 wave rows), 128x128 / 128x64 (2 wave rows), 256x32
+}
+
+#ifdef O2M_P8_STAMPS
+extern "C" int o2m_debug_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(o2m_p8_stamps), sizeof(unsigned long long) * 16);
+}
+#endif
+
+extern "C" int32_t o2m_conv2d_stats_rows(const o2m_conv_desc* d) {
+  if (!d || d->B <= 0 || d->H <= 0 || d->W <= 0 || d->KH <= 0 || d->KW <= 0 || d->pad < 0) return 0;
+  if (d->dtype != O2M_BF16 && d->dtype != O2M_F32) return 0;
+  const int S = d->stride > 1 ? d->stride : 1;
+  const long howo = (long)((d->H + 2 * d->pad - d->KH) / S + 1) * ((d->W + 2 * d->pad - d->KW) / S + 1);
+  const int r = stats_rows_for(*d);
+  return (r > 0 && howo > 0 && howo % r == 0) ? r : 0;
+}
+
 extern "C" int o2m_conv2d_fwd(const o2m_conv_desc* d, void* stream) {
   if (!d || !d->x || !d->w || !d->y) return O2M_ERR_BAD_ARG;
   if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Ci <= 0 || d->Co <= 0) return O2M_ERR_BAD_ARG;
@@ -837,6 +1248,8 @@ extern "C" int o2m_conv2d_fwd(const o2m_conv_desc* d, void* stream) {
     const long howo = (long)(d->H + 2 * d->pad - d->KH + 1) * (d->W + 2 * d->pad - d->KW + 1);
     if (howo % 256 != 0 || d->in_scale) return O2M_ERR_BAD_ARG;
   }
+  if (d->stats && (d->act != O2M_ACT_NONE || d->residual || d->out_scale || o2m_conv2d_stats_rows(d) == 0))
+    return O2M_ERR_BAD_ARG;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (d->dtype == O2M_BF16) return launch_dtype<unsigned short>(*d, s);
   if (d->dtype == O2M_F32) return launch_dtype<float>(*d, s);

@@ -638,7 +638,7 @@ inline unsigned grid_for(long n, int per_block = NT) {
 
 extern "C" {
 
-int o2m_abi_version(void) { return 12; }
+int o2m_abi_version(void) { return 13; }
 
 int o2m_modulate_weights(const float* w32, const float* s, void* out, int32_t B, int32_t Co,
                          int32_t KK, int32_t Ci, int32_t dtype, void* stream) {
@@ -715,6 +715,15 @@ int o2m_instnorm_stats(const void* x, float* partial, float* mean_rstd, int32_t 
   O2M_LAUNCH_CHECK();
   hipLaunchKernelGGL(in_finalize_kernel<0>, dim3((B * C + 255) / 256), dim3(256), 0, s, partial,
                      mean_rstd, B, P, C, gm.nchunks, eps);
+  O2M_LAUNCH_CHECK();
+  return 0;
+}
+
+int o2m_instnorm_finalize(const float* partial, float* mean_rstd, int32_t B, int32_t P, int32_t C,
+                          int32_t nchunks, float eps, void* stream) {
+  if (!partial || !mean_rstd || B <= 0 || P <= 0 || C <= 0 || nchunks <= 0) return O2M_ERR_BAD_ARG;
+  hipLaunchKernelGGL(in_finalize_kernel<0>, dim3((B * C + 255) / 256), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), partial, mean_rstd, B, P, C, nchunks, eps);
   O2M_LAUNCH_CHECK();
   return 0;
 }

@@ -88,8 +88,9 @@ inline void done(int err, const char* op, bool meta) {
 
 void conv2d_fwd(const Tensor& x, const Tensor& w, Tensor& y, const OptT& in_scale, const OptT& out_scale,
                 const OptT& bias, const OptT& residual, int64_t pad, int64_t pad_mode, int64_t act,
-                bool per_sample_w, int64_t stride) {
+                bool per_sample_w, int64_t stride, const std::optional<Tensor>& stats) {
   const char* op = "o2m::conv2d_fwd";
+  chk_f32(stats, op, "stats");
   chk(x, op, "x"); chk(w, op, "w"); chk(y, op, "y"); chk(residual, op, "residual");
   chk_f32(in_scale, op, "in_scale"); chk_f32(out_scale, op, "out_scale"); chk_f32(bias, op, "bias");
   TORCH_CHECK(x.dim() == 4 && y.dim() == 4 && w.dim() == (per_sample_w ? 5 : 4), op, ": x, y are NHWC; w is ",
@@ -115,7 +116,23 @@ void conv2d_fwd(const Tensor& x, const Tensor& w, Tensor& y, const OptT& in_scal
   d.act = i32(act, op); d.dtype = dtype_code(x, op);
   d.w_batch_stride = per_sample_w ? i32(Co * KH * KW * x.size(3), op) : 0;
   d.stride = i32(stride, op);
+  if (stats.has_value()) {
+    const int rows = o2m_conv2d_stats_rows(&d);
+    TORCH_CHECK(rows > 0, op, ": this conv cannot emit InstanceNorm partials (Ho*Wo is not a multiple of its row block)");
+    TORCH_CHECK(stats->numel() >= (x.size(0) * Ho * Wo / rows) * Co * 2, op, ": stats workspace too small");
+    d.stats = ptr<float>(stats);
+  }
   O2M_CALL(op, x, o2m_conv2d_fwd(&d, stream));
+}
+
+int64_t conv2d_stats_rows(const Tensor& x, const Tensor& w, const Tensor& y, int64_t pad, int64_t stride) {
+  const char* op = "o2m::conv2d_stats_rows";
+  TORCH_CHECK(x.dim() == 4 && w.dim() == 4 && y.dim() == 4, op, ": x, y are NHWC; w is [Co][KH][KW][Ci]");
+  o2m_conv_desc d{};
+  d.B = i32(x.size(0), op); d.H = i32(x.size(1), op); d.W = i32(x.size(2), op); d.Ci = i32(x.size(3), op);
+  d.Co = i32(w.size(0), op); d.KH = i32(w.size(1), op); d.KW = i32(w.size(2), op); d.pad = i32(pad, op);
+  d.dtype = dtype_code(x, op); d.stride = i32(stride, op);
+  return o2m_conv2d_stats_rows(&d);
 }
 
 void conv2d_wgrad(const Tensor& x, const Tensor& gy, Tensor& dw, const OptT& in_scale, const OptT& gy_scale,
@@ -257,6 +274,16 @@ void instnorm_stats(const Tensor& x, Tensor& partial, Tensor& mean_rstd, double 
   TORCH_CHECK(partial.numel() >= static_cast<int64_t>(o2m_instnorm_ws_floats(B, P, C)), op, ": workspace too small");
   const int dt_x = dtype_code(x, op);
   O2M_CALL(op, x, o2m_instnorm_stats(ptr(x), ptr<float>(partial), ptr<float>(mean_rstd), B, P, C, static_cast<float>(eps), dt_x, stream));
+}
+
+void instnorm_finalize(const Tensor& partial, Tensor& mean_rstd, int64_t P, int64_t nchunks, double eps) {
+  const char* op = "o2m::instnorm_finalize";
+  chk_f32(partial, op, "partial"); chk_f32(mean_rstd, op, "mean_rstd");
+  TORCH_CHECK(mean_rstd.dim() == 3 && mean_rstd.size(2) == 2, op, ": mean_rstd is [B][C][2]");
+  const int64_t B = mean_rstd.size(0), C = mean_rstd.size(1);
+  TORCH_CHECK(nchunks > 0 && partial.numel() >= B * nchunks * C * 2, op, ": partial is [B][nchunks][C][2]");
+  O2M_CALL(op, partial, o2m_instnorm_finalize(ptr<float>(partial), ptr<float>(mean_rstd), i32(B, op), i32(P, op), i32(C, op),
+                                           i32(nchunks, op), static_cast<float>(eps), stream));
 }
 
 void instnorm_apply(const Tensor& x, const Tensor& mean_rstd, const OptT& residual, Tensor& y, int64_t act) {
@@ -422,7 +449,9 @@ TORCH_LIBRARY(o2m, m) {
   m.def("instnorm_ws_floats(int B, int P, int C) -> int", &instnorm_ws_floats);
   m.def("reduce_blocks(int n) -> int", &reduce_blocks);
   m.def("conv2d_fwd(Tensor x, Tensor w, Tensor(a!) y, Tensor? in_scale, Tensor? out_scale, Tensor? bias, Tensor? residual, "
-        "int pad, int pad_mode, int act, bool per_sample_w, int stride) -> ()");
+        "int pad, int pad_mode, int act, bool per_sample_w, int stride, Tensor(b!)? stats=None) -> ()");
+  m.def("conv2d_stats_rows(Tensor x, Tensor w, Tensor y, int pad, int stride) -> int");
+  m.def("instnorm_finalize(Tensor partial, Tensor(a!) mean_rstd, int P, int nchunks, float eps) -> ()");
   m.def("conv2d_wgrad(Tensor x, Tensor gy, Tensor(a!) dw, Tensor? in_scale, Tensor? gy_scale, int pad, int pad_mode, int splits, "
         "Tensor[] more_x, Tensor[] more_gy, int stride) -> ()");
   m.def("wgrad_finalize(Tensor(a!) acc, Tensor(b!)? gq, Tensor w32, Tensor(c!) grad, int co, int ci, float c) -> ()");
@@ -463,6 +492,8 @@ TORCH_LIBRARY(o2m, m) {
   m.impl("act_bwd_reduce", &act_bwd_reduce);      \
   m.impl("fold_scale_dot", &fold_scale_dot);      \
   m.impl("instnorm_stats", &instnorm_stats);      \
+  m.impl("instnorm_finalize", &instnorm_finalize); \
+  m.impl("conv2d_stats_rows", &conv2d_stats_rows); \
   m.impl("instnorm_apply", &instnorm_apply);      \
   m.impl("instnorm_bwd", &instnorm_bwd);          \
   m.impl("resample2d", &resample2d);              \

@@ -44,10 +44,8 @@ class ResnetBlock(nn.Module):
             _Slot("InstanceNorm2d (+ residual add) -> instnorm kernels"))
 
     def run(self, t):
-        u = self.conv_block[1].run(t, reflect=1)
-        u = ops.instance_norm_act(u, H.ACT_RELU)
-        u = self.conv_block[5].run(u, reflect=1)
-        return ops.instance_norm_act(u, H.ACT_NONE, residual=t)
+        u = self.conv_block[1].run_norm_act(t, reflect=1, act=H.ACT_RELU)
+        return self.conv_block[5].run_norm_act(u, reflect=1, act=H.ACT_NONE, residual=t)
 
     def forward(self, x: torch.Tensor):
         return ops.to_public(self.run(ops.to_internal(x)), self.dim)

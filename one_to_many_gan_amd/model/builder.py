@@ -103,10 +103,10 @@ class Generator(nn.Module):
     # ---- fused plans on internal buffers -------------------------------------------------
     def _encode(self, t):
         mods = list(self.encoder)
-        t = ops.instance_norm_act(mods[1].run(t, reflect=3), H.ACT_RELU)
+        t = mods[1].run_norm_act(t, reflect=3, act=H.ACT_RELU)
         for m in mods[4:]:
             if isinstance(m, EqualisedConv2d):
-                t = ops.instance_norm_act(m.run(t), H.ACT_RELU)
+                t = m.run_norm_act(t, act=H.ACT_RELU)
             elif isinstance(m, (DownSample, ResnetBlock)):
                 t = m.run(t)
         return t
@@ -168,9 +168,9 @@ def _patch_trunk(input_nc: int):
 
 def _run_trunk(mods, t):
     t = mods[2].run(mods[0].run(t, act=H.ACT_LRELU))
-    t = mods[6].run(ops.instance_norm_act(mods[3].run(t), H.ACT_LRELU))
-    t = mods[10].run(ops.instance_norm_act(mods[7].run(t), H.ACT_LRELU))
-    return ops.instance_norm_act(mods[11].run(t), H.ACT_LRELU)
+    t = mods[6].run(mods[3].run_norm_act(t, act=H.ACT_LRELU))
+    t = mods[10].run(mods[7].run_norm_act(t, act=H.ACT_LRELU))
+    return mods[11].run_norm_act(t, act=H.ACT_LRELU)
 
 
 class Discriminator(nn.Module):

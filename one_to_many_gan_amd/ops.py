@@ -392,7 +392,7 @@ class _ConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, w_style, ts_weight, ts_bias, residual, prep, pad, pad_mode, act,
-                demodulate, eps):
+                demodulate, eps, stats_eps):
         w_f, w_d, q, w32, qt = prep.get()
         B, Hh, Ww, cip = x.shape
         if cip != prep.cip:
@@ -434,6 +434,22 @@ class _ConvFn(torch.autograd.Function):
             H.modulate_weights(w32, s, w_b)
             H.conv2d_fwd(x, w_b, y, out_scale=d, bias=bias_p, residual=residual, pad=pad,
                          pad_mode=pad_mode, act=act, per_sample_w=True)
+        elif stats_eps is not None:
+            # conv feeding an InstanceNorm: the epilogue emits the per-(sample, channel) partial sums
+            # of y on its way out, so the statistics pass over y is not run (odd-sized maps: fallback)
+            if s is not None or residual is not None or act != H.ACT_NONE:
+                raise RuntimeError("InstanceNorm statistics are emitted by plain convolutions only")
+            mr = torch.empty((B, prep.cop, 2), dtype=torch.float32, device=x.device)
+            rows = H.conv2d_stats_rows(x, w_f, y, pad=pad)
+            if rows:
+                nchunks = ho * wo // rows
+                part = torch.empty(B * nchunks * prep.cop * 2, dtype=torch.float32, device=x.device)
+                H.conv2d_fwd(x, w_f, y, bias=bias_p, pad=pad, pad_mode=pad_mode, act=act, stats=part)
+                H.instnorm_finalize(part, mr, ho * wo, nchunks, stats_eps)
+            else:
+                H.conv2d_fwd(x, w_f, y, bias=bias_p, pad=pad, pad_mode=pad_mode, act=act)
+                ws = torch.empty(H.instnorm_ws_floats(B, ho * wo, prep.cop), dtype=torch.float32, device=x.device)
+                H.instnorm_stats(y, ws, mr, stats_eps)
         else:
             H.conv2d_fwd(x, w_f, y, in_scale=s, out_scale=d, bias=bias_p, residual=residual,
                          pad=pad, pad_mode=pad_mode, act=act)
@@ -442,10 +458,13 @@ class _ConvFn(torch.autograd.Function):
         ctx.ts_params = (ts_weight, ts_bias)
         ctx.has_bias, ctx.has_res = bias is not None, residual is not None
         ctx.save_for_backward(x, y, residual, s, d, weight, bias_p, wv, ws)
+        if stats_eps is not None:
+            ctx.mark_non_differentiable(mr)  # InstanceNorm's backward carries the dependence on y itself
+            return y, mr
         return y
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, *_unused):
         x, y, residual, s, d, weight, bias_p, wv, ws = ctx.saved_tensors
         prep, pad, pad_mode, act = ctx.prep, ctx.pad, ctx.pad_mode, ctx.act
         w_f, w_d, q, _, _ = prep.get()
@@ -568,7 +587,7 @@ class _ConvFn(torch.autograd.Function):
             prep.use_reduced(dev)
         g_res = g if (ctx.has_res and need_res) else None
         return (g_x if need_x else None, None, g_bias, g_ws, g_tw, g_tb, g_res,
-                None, None, None, None, None, None)
+                None, None, None, None, None, None, None)
 
 
 # Debug tap (None in production): a list that receives, in execution order, the sign mask of every
@@ -584,13 +603,16 @@ def _tap_activation(y, act, residual):
 
 
 def conv2d(x, weight, bias, prep, *, pad, pad_mode=H.PAD_ZERO, act=H.ACT_NONE, style=None,
-           residual=None, demodulate=True, eps=1e-8):
-    """``style`` = (w, to_style.weight, to_style.bias) for the modulated conv, else None."""
+           residual=None, demodulate=True, eps=1e-8, norm_eps=None):
+    """``style`` = (w, to_style.weight, to_style.bias) for the modulated conv, else None.
+    ``norm_eps``: the conv feeds an InstanceNorm with this eps; returns ``(y, mean_rstd)`` with the
+    statistics of y ([B][C][2] fp32) for ``instance_norm_act(..., stats=mean_rstd)``."""
     w_style, ts_w, ts_b = style if style is not None else (None, None, None)
-    y = _ConvFn.apply(x, weight, bias, w_style, ts_w, ts_b, residual, prep, pad, pad_mode, act,
-                      demodulate, eps)
-    _tap_activation(y, act, residual)
-    return y
+    out = _ConvFn.apply(x, weight, bias, w_style, ts_w, ts_b, residual, prep, pad, pad_mode, act,
+                        demodulate, eps, norm_eps)
+    if norm_eps is None:
+        _tap_activation(out, act, residual)
+    return out
 
 
 # --------------------------------------------------------------------------- instance norm
@@ -600,11 +622,12 @@ class _InstNormFn(torch.autograd.Function):
     """y = act(InstanceNorm2d(x)) + residual  (eps 1e-5, biased variance, no affine)."""
 
     @staticmethod
-    def forward(ctx, x, residual, act, eps):
+    def forward(ctx, x, residual, act, eps, mr):
         B, Hh, Ww, Cn = x.shape
-        ws = torch.empty(H.instnorm_ws_floats(B, Hh * Ww, Cn), dtype=torch.float32, device=x.device)
-        mr = torch.empty((B, Cn, 2), dtype=torch.float32, device=x.device)
-        H.instnorm_stats(x, ws, mr, eps)
+        if mr is None:
+            ws = torch.empty(H.instnorm_ws_floats(B, Hh * Ww, Cn), dtype=torch.float32, device=x.device)
+            mr = torch.empty((B, Cn, 2), dtype=torch.float32, device=x.device)
+            H.instnorm_stats(x, ws, mr, eps)
         y = torch.empty_like(x)
         H.instnorm_apply(x, mr, residual, y, act)
         ctx.act = act
@@ -622,11 +645,12 @@ class _InstNormFn(torch.autograd.Function):
             gs = torch.empty((B, Cn, 2), dtype=torch.float32, device=x.device)
             gx = torch.empty_like(x)
             H.instnorm_bwd(g, x, mr, ws, gs, gx, ctx.act)
-        return gx, (g if ctx.needs_input_grad[1] else None), None, None
+        return gx, (g if ctx.needs_input_grad[1] else None), None, None, None
 
 
-def instance_norm_act(x, act=H.ACT_NONE, residual=None, eps=1e-5):
-    y = _InstNormFn.apply(x, residual, act, eps)
+def instance_norm_act(x, act=H.ACT_NONE, residual=None, eps=1e-5, stats=None):
+    """``stats``: mean / rstd of x already computed (by the epilogue of the conv that produced x)."""
+    y = _InstNormFn.apply(x, residual, act, eps, stats)
     _tap_activation(y, act, residual)
     return y
 

@@ -137,6 +137,64 @@ def test_full_size_adjoint_identities(shape, dt):
     assert float((y2.float() - 2 * y.float()).norm() / y2.float().norm()) < 1e-6
 
 
+FULL_SIZE_CONVS = [
+    # B, H, W, Ci, Co, k, pad, reflect, features              (bf16: which igemm kernel / tile)
+    (16, 64, 64, 256, 256, 3, 1, True, "plain"),     # phase-pipelined 256x256 kernel, one tile per CU
+    (32, 64, 64, 256, 256, 3, 1, True, "epilogue"),  # same, two waves of tiles; bias + act + residual
+    (16, 64, 64, 256, 256, 3, 1, True, "modulated"),  # per-sample filters + demodulation scale (decoder)
+    (16, 66, 66, 256, 256, 3, 2, False, "plain"),     # zero padding 2 = the data-gradient call shape
+    (8, 64, 64, 512, 512, 3, 1, True, "plain"),       # config #4: two N tiles, 72 K-tiles
+    (16, 128, 128, 128, 256, 3, 1, False, "epilogue"),  # Ci = 128: a tap is two K-tiles
+    (16, 256, 256, 128, 64, 3, 1, False, "epilogue"),  # N = 64 tile
+    (16, 128, 128, 256, 128, 3, 1, False, "modulated"),  # N = 128 tile, modulated
+]
+
+
+@pytest.mark.parametrize("case", FULL_SIZE_CONVS, ids=lambda c: "x".join(map(str, c[:7])) + "-" + c[8])
+def test_full_size_bf16_conv_matches_torch_fp32(case):
+    """The bf16 igemm kernels at BASELINE config #2 / #4 layer sizes -- too big for the CPU oracle --
+    against torch's own fp32 convolution of the SAME bf16-valued operands on the GPU.  The only
+    differences left are the summation order and the final rounding of y to bf16 (2^-9 relative per
+    element, ~1.2e-3 rms), so 3e-3 relative L2 catches any mis-staged tile, tap or K-tile."""
+    import torch.nn.functional as F
+
+    from one_to_many_gan_amd import _hip as H
+
+    B, Hh, Ww, Ci, Co, k, pad, reflect, feat = case
+    torch.manual_seed(17)
+    dev, dt = "cuda", torch.bfloat16
+    x = torch.randn(B, Hh, Ww, Ci, device=dev).to(dt)
+    ho, wo = Hh + 2 * pad - k + 1, Ww + 2 * pad - k + 1
+    y = torch.empty(B, ho, wo, Co, device=dev, dtype=dt)
+    kw = dict(pad=pad, pad_mode=H.PAD_REFLECT if reflect else H.PAD_ZERO, act=H.ACT_NONE)
+    w = (torch.randn((B if feat == "modulated" else 1), Co, k, k, Ci, device=dev) / (Ci * k * k) ** 0.5).to(dt)
+    scale = bias = res = None
+    if feat == "modulated":
+        scale = torch.rand(B, Co, device=dev) + 0.5
+        H.conv2d_fwd(x, w, y, out_scale=scale, per_sample_w=True, **kw)
+    elif feat == "epilogue":
+        bias = torch.randn(Co, device=dev)
+        res = torch.randn(B, ho, wo, Co, device=dev).to(dt)
+        kw["act"] = H.ACT_LRELU
+        H.conv2d_fwd(x, w[0], y, bias=bias, residual=res, **kw)
+    else:
+        H.conv2d_fwd(x, w[0], y, **kw)
+    xin = x.float().permute(0, 3, 1, 2)
+    xin = F.pad(xin, (pad,) * 4, mode="reflect") if reflect else F.pad(xin, (pad,) * 4)
+    if feat == "modulated":  # grouped conv with per-sample filters, as the reference runs it
+        ref = F.conv2d(xin.reshape(1, B * Ci, *xin.shape[2:]), w.float().permute(0, 1, 4, 2, 3).reshape(B * Co, Ci, k, k),
+                       groups=B).view(B, Co, ho, wo) * scale.view(B, Co, 1, 1)
+    else:
+        ref = F.conv2d(xin, w[0].float().permute(0, 3, 1, 2))
+    if feat == "epilogue":
+        ref = F.leaky_relu(ref + bias.view(1, -1, 1, 1), 0.2) + res.float().permute(0, 3, 1, 2)
+    ref = ref.permute(0, 2, 3, 1)
+    err = float((y.float() - ref).norm() / ref.norm())
+    assert err < 3e-3, err
+    worst = float((y.float() - ref).abs().max() / ref.abs().max())
+    assert worst < 2e-2, worst  # no single wrong tile hiding in the norm
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_rgb_tail_space_to_depth_path_is_self_adjoint(precision):
     """The 64 -> 3 7x7 reflect-padded tail conv runs as a stride-4 conv over 4x4 output blocks
