@@ -127,7 +127,8 @@ __device__ __attribute__((aligned(16))) unsigned int o2m_zero16[4] = {0u, 0u, 0u
 // WIDE: Ci % 64 == 0, so one 64-element stage lies inside ONE filter tap (tap-outer walk).
 // !WIDE: small Ci (image stems, Ci = 8..32): every 16-B chunk decodes its own tap.
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool IN_SCALE, bool WIDE>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(const o2m_conv_desc d) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(const o2m_conv_desc d, const int m_begin,
+                                                                                const int m_end) {
   constexpr int NT = 64 * WAVES_M * WAVES_N;
   constexpr bool F32 = sizeof(T) == 4;
   constexpr int NPLANE = F32 ? 2 : 1;  // hi (+ lo)
@@ -162,14 +163,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
   const int S = d.stride > 1 ? d.stride : 1;
   const int Ho = (H + 2 * pad - KH) / S + 1, Wo = (W + 2 * pad - KW) / S + 1;
   const int HoWo = Ho * Wo;
-  const int M = d.B * HoWo;
+  const int M = m_end;  // rows [m_begin, m_end) of the B * Ho * Wo output pixels (a launch may cover a slice)
   const int K = KH * KW * Ci;
   const int nk = (K + BK - 1) / BK;
   const bool reflect = d.pad_mode == O2M_PAD_REFLECT;
 
   const int tiles_n = (Co + BN - 1) / BN;
   const int tile = xcd_tile_order(blockIdx.x, gridDim.x);
-  const int m0 = (tile / tiles_n) * BM;
+  const int m0 = m_begin + (tile / tiles_n) * BM;
   const int n0 = (tile % tiles_n) * BN;
 
   // sample of the tile's first pixel; uniform over the tile when it does not straddle samples
@@ -501,7 +502,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
       }
       store8(Y + off, o);
     }
-    if (d.stats) {
+    if (d.stats && mbase < M) {  // (a tile's trailing passes can lie past the problem: nothing to report)
       if constexpr (NT % VPR == 0 && VPR * 16 <= NT)
         stats_block_reduce<NT, VPR>(st, csm, d.stats, (long)(mbase / WM), n0, Co, tid);
     }
@@ -516,6 +517,13 @@ constexpr int lds_bytes() {
   constexpr int lds_epi = (BM / WAVES_M) * (BN + 4) * 4;
   return lds_main > lds_epi ? lds_main : lds_epi;
 }
+
+inline long out_rows(const o2m_conv_desc& d) {
+  const int S = d.stride > 1 ? d.stride : 1;
+  return (long)d.B * ((d.H + 2 * d.pad - d.KH) / S + 1) * ((d.W + 2 * d.pad - d.KW) / S + 1);
+}
+template <int BM, int BN>
+long tiles_rows(const o2m_conv_desc& d, long rows) { return ((rows + BM - 1) / BM) * ((d.Co + BN - 1) / BN); }
 
 template <int BM, int BN>
 long tiles_for(const o2m_conv_desc& d) {
@@ -574,7 +582,10 @@ __device__ unsigned long long o2m_p8_stamps[2][8];
 #define P8_STAMP(i) do {} while (0)
 #endif
 
-__global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_desc d) {
+// SPLIT: the second fill of a phase's region is issued in the middle of the MFMA segment instead of
+// the load segment (a fill costs the issuing wave ~165 cycles there: s_memtime stamps, r02 profiles).
+template <bool SPLIT>
+__global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_desc d, const int m_begin, const int m_end) {
   using T = unsigned short;
   constexpr int BM = 256, BN = 256, NT = 512;
   constexpr int OPB = 32768;   // one operand of one K-tile: 256 rows x 128 B
@@ -584,14 +595,14 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
   const int H = d.H, W = d.W, Ci = d.Ci, Co = d.Co, KH = d.KH, KW = d.KW, pad = d.pad;
   const int Ho = H + 2 * pad - KH + 1, Wo = W + 2 * pad - KW + 1;
   const int HoWo = Ho * Wo;
-  const int M = d.B * HoWo;
+  const int M = m_end;  // rows [m_begin, m_end) of the B * Ho * Wo output pixels (a launch may cover a slice)
   const int K = KH * KW * Ci;
   const int nk = K / BK;
   const bool reflect = d.pad_mode == O2M_PAD_REFLECT;
 
   const int tiles_n = (Co + BN - 1) / BN;
   const int tile = xcd_tile_order(blockIdx.x, gridDim.x);
-  const int m0 = (tile / tiles_n) * BM;
+  const int m0 = m_begin + (tile / tiles_n) * BM;
   const int n0 = (tile % tiles_n) * BN;
   const int b_first = m0 / HoWo;
   const bool b_uniform = (min(m0 + BM, M) - 1) / HoWo == b_first;
@@ -638,8 +649,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
   int a_ky[2] = {0, 0}, a_kx[2] = {0, 0}, a_cb[2] = {0, 0}, a_buf[2] = {0, 0};
   int b_kt[2] = {0, 0};
 
-  auto issue_a = [&](int r) {
-    if (a_cb[r] == 0) {  // first K-tile of a tap: gather offsets of this region's two fills
+  auto issue_a = [&](int r, int part) {  // part: 0 = whole region, 1 / 2 = its first / second fill only
+    if (part != 2 && a_cb[r] == 0) {  // first K-tile of a tap: gather offsets of this region's two fills
       const int dy = a_ky[r] - pad, dx = a_kx[r] - pad;
       const bool live = a_ky[r] < KH;  // past the reduction: zero fills, no traffic
 #pragma unroll
@@ -660,9 +671,11 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
     char* dst = smem + a_buf[r] * BUFB;
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
+      if (part == 1 + (1 - jj)) continue;
       const int j = 2 * r + jj;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void*)(dst + a_group(j) * 1024), 16, (int)aoff[j], a_cb[r] * 2, 0, 0);
     }
+    if (part == 1) return;
     a_buf[r] ^= 1;
     a_cb[r] += BK;
     if (a_cb[r] == Ci) {
@@ -670,16 +683,17 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
       if (++a_kx[r] == KW) { a_kx[r] = 0; ++a_ky[r]; }
     }
   };
-  auto issue_b = [&](int r) {
+  auto issue_b = [&](int r, int part) {
     const bool live = b_kt[r] < nk;
     char* dst = smem + (b_kt[r] & 1) * BUFB + OPB;
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
+      if (part == 1 + (1 - jj)) continue;
       const int j = 2 * r + jj;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void*)(dst + b_group(j) * 1024), 16,
                                                (int)(live ? dwoff[j] : OOB_OFF), b_kt[r] * (BK * 2), 0, 0);
     }
-    ++b_kt[r];
+    if (part != 1) ++b_kt[r];
   };
 
   // ---- fragments ------------------------------------------------------------------------------------
@@ -711,18 +725,21 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  auto multiply = [&](const bf16x8 (&bf)[2][2], int mh, int nh) {
+  auto multiply = [&](const bf16x8 (&bf)[2][2], int mh, int nh, auto&& midway) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+    for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           acc[mh * 4 + i][nh * 2 + j] =
               __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][ks], bf[j][ks], acc[mh * 4 + i][nh * 2 + j], 0, 0, 0);
+      if (ks == 0) midway();
+    }
     __builtin_amdgcn_s_setprio(0);
   };
+  auto nothing = [] {};
 #ifdef O2M_P8_STAMPS
   unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0;
 #endif
@@ -730,7 +747,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
 #define P8_WAIT_AND_SYNC()                                  \
   do {                                                      \
     P8_STAMP(0);                                            \
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        \
+    if constexpr (SPLIT) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");  \
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   \
     P8_STAMP(1);                                            \
     __builtin_amdgcn_s_barrier();                           \
     P8_STAMP(2);                                            \
@@ -743,43 +761,53 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
   } while (0)
 
   // ---- prologue: regions needed by phases -1 .. 4 -------------------------------------------------------
-  issue_b(0);  // B0(0)
-  issue_a(0);  // A0(0)
-  issue_b(1);  // B1(0)
-  issue_a(1);  // A1(0)
-  issue_b(0);  // B0(1)
-  issue_a(0);  // A0(1)
-  P8_WAIT_AND_SYNC();                           // B0(0), A0(0) have landed for every wave
+  issue_b(0, 0);  // B0(0)
+  issue_a(0, 0);  // A0(0)
+  issue_b(1, 0);  // B1(0)
+  issue_a(1, 0);  // A1(0)
+  issue_b(0, 0);  // B0(1)
+  issue_a(0, 0);  // A0(1)
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // B0(0), A0(0) have landed for every wave
+  __builtin_amdgcn_s_barrier();
   if (wrow == 1) __builtin_amdgcn_s_barrier();  // this wave row runs one barrier behind the other
   read_b(b0f, 0, 0);
 #ifdef O2M_P8_STAMPS
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
+  for (int i = 0; i < 8; ++i) st_sum[i] = 0;
 #endif
 
   for (int t = 0; t < nk; ++t) {
     const int cur = t & 1;
     // p1: A0 x B0
     read_a(cur, 0);
-    issue_b(1);  // B1(t+1)
+    P8_STAMP(5);
+    issue_b(1, SPLIT ? 1 : 0);  // B1(t+1)
     P8_WAIT_AND_SYNC();
-    multiply(b0f, 0, 0);
+    if constexpr (SPLIT) multiply(b0f, 0, 0, [&] { issue_b(1, 2); });
+    else multiply(b0f, 0, 0, nothing);
     P8_CLOSE();
     // p2: A0 x B1
     read_b(b1f, cur, 1);
-    issue_a(1);  // A1(t+1)
+    P8_STAMP(5);
+    issue_a(1, SPLIT ? 1 : 0);  // A1(t+1)
     P8_WAIT_AND_SYNC();
-    multiply(b1f, 0, 1);
+    if constexpr (SPLIT) multiply(b1f, 0, 1, [&] { issue_a(1, 2); });
+    else multiply(b1f, 0, 1, nothing);
     P8_CLOSE();
     // p3: A1 x B1
     read_a(cur, 1);
-    issue_b(0);  // B0(t+2)
+    P8_STAMP(5);
+    issue_b(0, SPLIT ? 1 : 0);  // B0(t+2)
     P8_WAIT_AND_SYNC();
-    multiply(b1f, 1, 1);
+    if constexpr (SPLIT) multiply(b1f, 1, 1, [&] { issue_b(0, 2); });
+    else multiply(b1f, 1, 1, nothing);
     P8_CLOSE();
     // p4: A1 x B0, then the next K-tile's B0 fragments (landed: waited for at the end of p3)
-    issue_a(0);  // A0(t+2)
+    P8_STAMP(5);
+    issue_a(0, SPLIT ? 1 : 0);  // A0(t+2)
     P8_WAIT_AND_SYNC();
-    multiply(b0f, 1, 0);
+    if constexpr (SPLIT) multiply(b0f, 1, 0, [&] { issue_a(0, 2); });
+    else multiply(b0f, 1, 0, nothing);
     read_b(b0f, cur ^ 1, 0);
     P8_CLOSE();
   }
@@ -854,19 +882,19 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
       }
       store8(Y + off, o);
     }
-    if (d.stats) stats_block_reduce<NT, VPR>(st, csm, d.stats, (long)(mbase / 128), n0, Co, tid);
+    if (d.stats && mbase < M) stats_block_reduce<NT, VPR>(st, csm, d.stats, (long)(mbase / 128), n0, Co, tid);
     if (pass == 0) __syncthreads();
   }
 }
 
-int launch_p8(const o2m_conv_desc& d, hipStream_t s) {
+int launch_p8(const o2m_conv_desc& d, hipStream_t s, int variant, long m_begin, long m_end) {
   constexpr int lds_main = 2 * 65536, lds_epi = 128 * (256 + 4) * 4;
   constexpr int lds = lds_main > lds_epi ? lds_main : lds_epi;
-  const long tiles = tiles_for<256, 256>(d);
+  const long tiles = tiles_rows<256, 256>(d, m_end - m_begin);
   if (tiles <= 0 || tiles > 0x7fffffffL) return O2M_ERR_BAD_ARG;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_p8_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  hipLaunchKernelGGL(conv_igemm_p8_kernel, dim3((unsigned)tiles), dim3(512), lds, s, d);
+  auto kern = variant == 2 ? conv_igemm_p8_kernel<true> : conv_igemm_p8_kernel<false>;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), lds, s, d, (int)m_begin, (int)m_end);
   O2M_LAUNCH_CHECK();
   return 0;
 }
@@ -1139,15 +1167,16 @@ int launch_ws(const o2m_conv_desc& d, hipStream_t s) {
 }
 
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
-int launch_cfg(const o2m_conv_desc& d, hipStream_t s) {
+int launch_cfg(const o2m_conv_desc& d, hipStream_t s, long m_begin = 0, long m_end = -1) {
   constexpr int lds = lds_bytes<T, BM, BN, WAVES_M, WAVES_N>();
   constexpr int NT = 64 * WAVES_M * WAVES_N;
-  const long tiles = tiles_for<BM, BN>(d);
+  if (m_end < 0) m_end = out_rows(d);
+  const long tiles = tiles_rows<BM, BN>(d, m_end - m_begin);
   if (tiles <= 0 || tiles > 0x7fffffffL) return O2M_ERR_BAD_ARG;
   auto go = [&](auto kern) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(NT), lds, s, d);
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(NT), lds, s, d, (int)m_begin, (int)m_end);
   };
   const bool wide = d.Ci % BK == 0;
   if (d.in_scale) {
@@ -1181,8 +1210,23 @@ int launch_dtype(const o2m_conv_desc& d, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {
       // O2M_IGEMM_P8=0: the symmetric two-stage kernel instead of the phase-pipelined one (A/B runs)
       static const int p8 = [] { const char* e = getenv("O2M_IGEMM_P8"); return e ? atoi(e) : 1; }();
-      if (p8 && !d.in_scale && d.stride <= 1 && d.Ci % BK == 0 && tiles_for<256, 256>(d) >= kFillBlocks)
-        return launch_p8(d, s);
+      if (p8 && !d.in_scale && d.stride <= 1 && d.Ci % BK == 0 && tiles_for<256, 256>(d) >= kFillBlocks) {
+        // One block per CU and round: a few tiles past a whole number of rounds would cost a whole
+        // extra round (the data gradient of the reflect-padded 64x64 layers is 273 tiles = 2 rounds for
+        // 1.07 rounds of work).  Such a tail (<= 1/4 round) runs as a second launch of 128x128 tiles
+        // over the last rows instead: 256 + 17 tiles take 1 round + ~0.3 instead of 2.
+        const long rows = out_rows(d), tn = (d.Co + 255) / 256, tiles = tiles_for<256, 256>(d);
+        const long tail = tiles % kFillBlocks;
+        static const int split_tail = [] { const char* e = getenv("O2M_IGEMM_TAIL_SPLIT"); return e ? atoi(e) : 1; }();
+        if (split_tail && tiles > kFillBlocks && tail > 0 && tail <= kFillBlocks / 4 && (tiles - tail) % tn == 0 &&
+            !d.stats) {
+          const long m_split = (tiles - tail) / tn * 256;
+          const int rc = launch_p8(d, s, p8, 0, m_split);
+          if (rc) return rc;
+          return launch_cfg<T, 128, 128, 2, 2>(d, s, m_split, rows);
+        }
+        return launch_p8(d, s, p8, 0, rows);
+      }
     }
     if (tiles_for<256, 256>(d) >= kFillBlocks) return launch_cfg<T, 256, 256, 2, 4>(d, s);
     return launch_cfg<T, 128, 128, 2, 2>(d, s);

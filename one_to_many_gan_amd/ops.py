@@ -273,6 +273,8 @@ _DIRECT_STYLE_GRADS = _os.environ.get("O2M_DIRECT_STYLE_GRADS", "0") == "1"
 # _finalize_weight_grads needs them), so they can run on their own stream next to the HBM-bound
 # pointwise kernels of the following layers.
 _WGRAD_STREAM = _os.environ.get("O2M_WGRAD_STREAM", "0") == "1"
+# O2M_FUSED_IN_STATS=0: InstanceNorm statistics by their own pass over the conv output (A/B runs)
+_FUSED_IN_STATS = _os.environ.get("O2M_FUSED_IN_STATS", "1") == "1"
 # O2M_EARLY_FINALIZE=0 falls back to finalising every filter gradient in the end-of-backward callback
 _EARLY_FINALIZE = _os.environ.get("O2M_EARLY_FINALIZE", "1") == "1"
 _WSTREAM: dict = {}
@@ -374,6 +376,40 @@ def _finalize_weight_grads():
             _finalize_layer(prep)
 
 
+class _ZeroPool:
+    """Pre-zeroed fp32 scratch for the atomically accumulated per-(sample, channel) tables of the conv
+    backward (``sums`` / ``dots``): ~60 of them per generator step, each a few KB, each costing a
+    ``torch.zeros`` fill launch.  Slices are handed out bump-pointer style from one buffer that is
+    cleared by ONE memset per optimiser ``zero_grad`` (``reset``), when no backward temporaries are
+    alive; a request that does not fit falls back to ``torch.zeros``."""
+
+    CAPACITY = 4 << 20  # floats (16 MB)
+
+    def __init__(self):
+        self.buf, self.used, self.dirty = {}, {}, {}
+
+    def take(self, n: int, device) -> torch.Tensor:
+        buf = self.buf.get(device)
+        if buf is None:
+            buf = self.buf[device] = torch.zeros(self.CAPACITY, dtype=torch.float32, device=device)
+            self.used[device] = 0
+        off = self.used[device]
+        n4 = (n + 3) // 4 * 4  # 16-B aligned slices
+        if off + n4 > self.CAPACITY:
+            return torch.zeros(n, dtype=torch.float32, device=device)
+        self.used[device] = off + n4
+        return buf[off: off + n]
+
+    def reset(self):
+        for device, buf in self.buf.items():
+            if self.used[device]:
+                buf[: self.used[device]].zero_()
+                self.used[device] = 0
+
+
+ZERO_POOL = _ZeroPool()
+
+
 def _pad_cols(t: torch.Tensor, n: int) -> torch.Tensor:
     t = t.float()
     if t.shape[1] == n:
@@ -440,7 +476,7 @@ class _ConvFn(torch.autograd.Function):
             if s is not None or residual is not None or act != H.ACT_NONE:
                 raise RuntimeError("InstanceNorm statistics are emitted by plain convolutions only")
             mr = torch.empty((B, prep.cop, 2), dtype=torch.float32, device=x.device)
-            rows = H.conv2d_stats_rows(x, w_f, y, pad=pad)
+            rows = H.conv2d_stats_rows(x, w_f, y, pad=pad) if _FUSED_IN_STATS else 0
             if rows:
                 nchunks = ho * wo // rows
                 part = torch.empty(B * nchunks * prep.cop * 2, dtype=torch.float32, device=x.device)
@@ -480,7 +516,7 @@ class _ConvFn(torch.autograd.Function):
         want_dots = s is not None and (need_x or need_s or (need_w and d is not None))
         if want_sums or want_dots:  # one zero-fill for both atomically accumulated tables
             ns, nd = (B * 2 * prep.cop if want_sums else 0), (B * cip if want_dots else 0)
-            z = torch.zeros(ns + nd, dtype=torch.float32, device=dev)
+            z = ZERO_POOL.take(ns + nd, dev)
             sums = z[:ns].view(B, 2, prep.cop) if want_sums else None
             dots = z[ns:].view(B, cip) if want_dots else None
         if act != H.ACT_NONE or d is not None:

@@ -67,6 +67,7 @@ class FusedAdam:
 
     def zero_grad(self, set_to_none: bool = False):
         self.bucket.zero_grad()
+        ops.ZERO_POOL.reset()  # between steps: no backward temporaries are alive
 
     def step(self):
         for hook in self.pre_step_hooks:

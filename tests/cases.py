@@ -440,7 +440,9 @@ def run_case_shared_masks(name, product_namespace, oracle_namespace):
     count = [0, 0]
 
     def replay(kind, t, inplace):
-        m = next(masks)[:, : t.shape[1]]
+        # .contiguous(): the tap hands out NHWC-strided views; with them torch's CPU kernels switch the
+        # oracle to channels-last tensors, whose float64 path returned wrong gradients at batch 1
+        m = next(masks)[:, : t.shape[1]].contiguous()
         assert m.shape == t.shape, (kind, tuple(m.shape), tuple(t.shape))
         count[0] += int(((t.detach() > 0) != m).sum())
         count[1] += m.numel()

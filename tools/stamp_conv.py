@@ -17,8 +17,8 @@ buf = (ctypes.c_ulonglong * 16)()
 H.lib().o2m_debug_stamps.argtypes = [ctypes.c_void_p]
 print("rc", H.lib().o2m_debug_stamps(buf))
 v = list(buf)
-names = ["reads+fill issue", "vmcnt wait", "barrier->mfma", "mfma issue", "closing barrier"]
+names = ["fill issue", "vmcnt wait", "barrier->mfma", "mfma issue", "closing barrier", "lds reads (issue+return)"]
 nph = 36 * 4
 for g in range(2):
-    a = v[g * 8: g * 8 + 5]
+    a = v[g * 8: g * 8 + 6]
     print(f"wave row {g}: cycles per PHASE: " + "  ".join(f"{n} {c / nph:.0f}" for n, c in zip(names, a)) + f"  total {sum(a) / nph:.0f}")
