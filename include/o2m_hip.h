@@ -156,11 +156,19 @@ typedef struct {
                             Wo % 32 == 0 and no in_scale / gy_scale. */
   int32_t stride;        /* 0/1: unit stride; >1: gy is the output of a strided conv
                             (Ho = (H + 2 pad - KH) / stride + 1)                          */
-  int32_t reserved[3];
+  int32_t reserved[1];
+  float* slabs;          /* NULL: the pixel slices add into dw with fp32 atomics (arrival order: the last
+                            bits differ from run to run).  Otherwise a workspace of
+                            o2m_conv2d_wgrad_slab_floats(d) floats: every slice STORES its Co x K partial
+                            there and a second kernel adds the slices to dw in slice order -- bitwise
+                            reproducible (the reference's deterministic_cuda_kernels switch, train.py:41-45)
+                            and faster: plain stores run at ~4-5x the chip-wide float-atomic rate. */
   const void* x_seg[8];  /* [0] ignored (= x)  */
   const void* gy_seg[8]; /* [0] ignored (= gy) */
 } o2m_wgrad_desc;
 int o2m_conv2d_wgrad(const o2m_wgrad_desc* d, void* stream);
+/* Floats of slab workspace o2m_conv2d_wgrad needs for this problem (0 for an invalid descriptor). */
+size_t o2m_conv2d_wgrad_slab_floats(const o2m_wgrad_desc* d);
 
 /* End-of-backward conversion of an accumulated weight gradient to the parameter layout:
  *   grad[o][i][kh][kw] += c * ( acc[o][kh][kw][i] + 2 * gq[o][i] * w32[o][kh][kw][i] )

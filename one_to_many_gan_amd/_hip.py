@@ -32,7 +32,7 @@ BF16, F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 PAD_ZERO, PAD_REFLECT = 0, 1
 RED_L1, RED_SQ, RED_MOM = 0, 1, 2
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -49,7 +49,8 @@ class WgradDesc(C.Structure):
     _fields_ = [("x", _vp), ("gy", _vp), ("dw", _vp), ("in_scale", _vp), ("gy_scale", _vp),
                 ("B", _i32), ("H", _i32), ("W", _i32), ("Ci", _i32), ("Co", _i32), ("KH", _i32),
                 ("KW", _i32), ("pad", _i32), ("pad_mode", _i32), ("dtype", _i32), ("splits", _i32),
-                ("nseg", _i32), ("stride", _i32), ("reserved", _i32 * 3), ("x_seg", _vp * 8), ("gy_seg", _vp * 8)]
+                ("nseg", _i32), ("stride", _i32), ("reserved", _i32 * 1), ("slabs", _vp), ("x_seg", _vp * 8),
+                ("gy_seg", _vp * 8)]
 
 
 # name -> (restype, argtypes); mirrors include/o2m_hip.h one for one
@@ -59,6 +60,7 @@ SIGNATURES = {
     "o2m_conv2d_stats_rows": (_i32, [C.POINTER(ConvDesc)]),
     "o2m_instnorm_finalize": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),
     "o2m_conv2d_wgrad": (_i32, [C.POINTER(WgradDesc), _vp]),
+    "o2m_conv2d_wgrad_slab_floats": (C.c_size_t, [C.POINTER(WgradDesc)]),
     "o2m_wgrad_finalize": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
     "o2m_style_fwd": (_i32, [_vp] * 6 + [_i32] * 5 + [_f32, _f32, _vp]),
     "o2m_style_bwd": (_i32, [_vp] * 14 + [_i32] * 5 + [_f32, _i32, _vp]),
@@ -228,15 +230,32 @@ def conv2d_stats_rows(x, w, y, *, pad, stride=1):
     return ops().conv2d_stats_rows(x, w, y, pad, stride)
 
 
+_SLABS: dict = {}  # device -> fp32 workspace of the slice partials (grown on demand, reused by every launch)
+WGRAD_ATOMICS = os.environ.get("O2M_WGRAD_ATOMICS", "0") == "1"  # A/B: float atomics instead of slab + reduce
+
+
+def _slab_workspace(x, gy, dw, pad, pad_mode, splits, n_more, stride):
+    if WGRAD_ATOMICS:
+        return None
+    need = ops().conv2d_wgrad_slab_floats(x, gy, dw, pad, pad_mode, splits, n_more, stride)
+    ws = _SLABS.get(x.device)
+    if ws is None or ws.numel() < need:
+        ws = _SLABS[x.device] = torch.empty(max(need, 16 << 20), dtype=torch.float32, device=x.device)
+    return ws
+
+
 def conv2d_wgrad(x, gy, dw, *, in_scale=None, gy_scale=None, pad, pad_mode, splits=0, more=(), stride=1):
-    """``more``: extra (x, gy) pairs of the same shape reduced by the same launch (<= 7)."""
+    """``more``: extra (x, gy) pairs of the same shape reduced by the same launch (<= 7).
+    The pixel slices go through a slab workspace + ordered second-stage sum (deterministic; see
+    o2m_wgrad_desc.slabs) unless O2M_WGRAD_ATOMICS=1."""
     mx, mg = [p[0] for p in more], [p[1] for p in more]
+    slabs = _slab_workspace(x, gy, dw, pad, pad_mode, splits, len(more), stride)
     if PROFILE is None:
-        return ops().conv2d_wgrad(x, gy, dw, in_scale, gy_scale, pad, pad_mode, splits, mx, mg, stride)
+        return ops().conv2d_wgrad(x, gy, dw, in_scale, gy_scale, pad, pad_mode, splits, mx, mg, stride, slabs)
     Co, KH, KW, Ci = dw.shape
     m = (1 + len(more)) * gy.shape[0] * gy.shape[1] * gy.shape[2]
     _timed(_wgrad_name(x.dtype, Co, m, KH * KW * Ci), 2.0 * m * Co * KH * KW * Ci, x,
-           lambda: ops().conv2d_wgrad(x, gy, dw, in_scale, gy_scale, pad, pad_mode, splits, mx, mg, stride))
+           lambda: ops().conv2d_wgrad(x, gy, dw, in_scale, gy_scale, pad, pad_mode, splits, mx, mg, stride, slabs))
 
 
 def act_bwd_reduce(g, y, residual, out_mul, gu, sums, act):

@@ -342,13 +342,34 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const o2m_wgrad_desc 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = co0 + wco + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (co < Co) atomicAdd(d.dw + (size_t)co * K + k, acc[i][j][r]);
+        if (co < Co) {
+          // slab mode: this slice's partial is stored (one writer per element), summed in slice order
+          // by wgrad_reduce_kernel; else fp32 atomics straight into dw
+          if (d.slabs) d.slabs[((size_t)split * Co + co) * K + k] = acc[i][j][r];
+          else atomicAdd(d.dw + (size_t)co * K + k, acc[i][j][r]);
+        }
       }
   }
 }
 
+// dw[i] += sum over the slices, in slice order (fixed summation order: bitwise reproducible)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(float* __restrict__ dw, const float* __restrict__ slabs,
+                                                           int splits, long n4) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const f32x4* src = reinterpret_cast<const f32x4*>(slabs) + i;
+  f32x4 acc = reinterpret_cast<const f32x4*>(dw)[i];
+#pragma unroll 4
+  for (int s = 0; s < splits; ++s) {
+    const f32x4 v = src[(size_t)s * n4];
+    acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+  }
+  reinterpret_cast<f32x4*>(dw)[i] = acc;
+}
+
+// slab_floats != nullptr: only report the workspace the launch would need
 template <typename T, int BCO, int BKO, int WAVES_CO, int WAVES_K>
-int launch_cfg(const o2m_wgrad_desc& d, hipStream_t s) {
+int launch_cfg(const o2m_wgrad_desc& d, hipStream_t s, size_t* slab_floats = nullptr) {
   constexpr bool F32 = sizeof(T) == 4;
   constexpr int lds = 2 * (F32 ? 2 : 1) * BMR * ((BCO * 2 + 64) + (BKO * 2 + 64));
   const int st = d.stride > 0 ? d.stride : 1;
@@ -377,6 +398,10 @@ int launch_cfg(const o2m_wgrad_desc& d, hipStream_t s) {
   splits = (M + rows - 1) / rows;
   const long blocks = splits * tiles_co * tiles_k;
   if (blocks > 0x7fffffffL) return O2M_ERR_BAD_ARG;
+  if (slab_floats) {
+    *slab_floats = (size_t)splits * d.Co * K;
+    return 0;
+  }
   auto go = [&](auto kern) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -393,11 +418,17 @@ int launch_cfg(const o2m_wgrad_desc& d, hipStream_t s) {
   if (Wo % BMR == 0) pick(std::true_type{});
   else pick(std::false_type{});
   O2M_LAUNCH_CHECK();
+  if (d.slabs) {
+    const long n4 = (long)d.Co * K / 4;  // Ci % 8 == 0, so K % 8 == 0
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, d.dw, d.slabs,
+                       (int)splits, n4);
+    O2M_LAUNCH_CHECK();
+  }
   return 0;
 }
 
 template <typename T>
-int launch_dtype(const o2m_wgrad_desc& d, hipStream_t s) {
+int launch_dtype(const o2m_wgrad_desc& d, hipStream_t s, size_t* slab_floats = nullptr) {
   // O2M_WGRAD_TILES=small keeps the 128-wide tiles (A/B measurements)
   static const bool small = [] { const char* e = getenv("O2M_WGRAD_TILES"); return e && e[0] == 's'; }();
   const int K = d.KH * d.KW * d.Ci;
@@ -407,19 +438,28 @@ int launch_dtype(const o2m_wgrad_desc& d, hipStream_t s) {
     const int st = d.stride > 0 ? d.stride : 1;
     const long M = (long)(d.nseg > 1 ? d.nseg : 1) * d.B * ((d.H + 2 * d.pad - d.KH) / st + 1) *
                    ((d.W + 2 * d.pad - d.KW) / st + 1);
-    if (d.Co > 256 || (d.Co > 128 && M >= 100000)) return launch_cfg<T, 256, 128, 2, 2>(d, s);
+    if (d.Co > 256 || (d.Co > 128 && M >= 100000)) return launch_cfg<T, 256, 128, 2, 2>(d, s, slab_floats);
     if (d.Co > 64 && d.Co <= 128 && K % 256 == 0 && sizeof(T) == 2)  // fp32 split: would spill
-      return launch_cfg<T, 128, 256, 2, 2>(d, s);
+      return launch_cfg<T, 128, 256, 2, 2>(d, s, slab_floats);
   }
-  if (d.Co > 64) return launch_cfg<T, 128, 128, 2, 2>(d, s);
-  if (d.Co > 32) return launch_cfg<T, 64, 128, 2, 2>(d, s);
-  return launch_cfg<T, 32, 128, 1, 4>(d, s);
+  if (d.Co > 64) return launch_cfg<T, 128, 128, 2, 2>(d, s, slab_floats);
+  if (d.Co > 32) return launch_cfg<T, 64, 128, 2, 2>(d, s, slab_floats);
+  return launch_cfg<T, 32, 128, 1, 4>(d, s, slab_floats);
 }
 
 }  // namespace
 
-extern "C" int o2m_conv2d_wgrad(const o2m_wgrad_desc* d, void* stream) {
-  if (!d || !d->x || !d->gy || !d->dw) return O2M_ERR_BAD_ARG;
+static int wgrad_run(const o2m_wgrad_desc* d, void* stream, size_t* slab_floats);
+
+extern "C" size_t o2m_conv2d_wgrad_slab_floats(const o2m_wgrad_desc* d) {
+  size_t n = 0;
+  return wgrad_run(d, nullptr, &n) == 0 ? n : 0;
+}
+
+extern "C" int o2m_conv2d_wgrad(const o2m_wgrad_desc* d, void* stream) { return wgrad_run(d, stream, nullptr); }
+
+static int wgrad_run(const o2m_wgrad_desc* d, void* stream, size_t* slab_floats) {
+  if (!d || ((!d->x || !d->gy || !d->dw) && !slab_floats)) return O2M_ERR_BAD_ARG;
   if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Ci <= 0 || d->Co <= 0) return O2M_ERR_BAD_ARG;
   if ((d->Ci & 7) || (d->Co & 7) || d->KH <= 0 || d->KW <= 0 || d->pad < 0) return O2M_ERR_BAD_ARG;
   if (d->H + 2 * d->pad < d->KH || d->W + 2 * d->pad < d->KW) return O2M_ERR_BAD_ARG;
@@ -440,7 +480,7 @@ extern "C" int o2m_conv2d_wgrad(const o2m_wgrad_desc* d, void* stream) {
       if (!d->x_seg[i] || !d->gy_seg[i]) return O2M_ERR_BAD_ARG;
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (d->dtype == O2M_BF16) return launch_dtype<unsigned short>(*d, s);
-  if (d->dtype == O2M_F32) return launch_dtype<float>(*d, s);
+  if (d->dtype == O2M_BF16) return launch_dtype<unsigned short>(*d, s, slab_floats);
+  if (d->dtype == O2M_F32) return launch_dtype<float>(*d, s, slab_floats);
   return O2M_ERR_BAD_ARG;
 }

@@ -37,6 +37,30 @@ def test_wgrad_multi_segment_equals_separate_launches(dt):
         H.conv2d_wgrad(bad[0], badg[0], one, pad=1, pad_mode=H.PAD_REFLECT, more=[(bad[1], badg[1])])
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32], ids=["bf16", "fp32"])
+def test_wgrad_is_bitwise_reproducible(dt):
+    """Slab mode (default): every pixel slice stores its partial and a second kernel sums the slices
+    in slice order, so two launches on the same operands agree bit for bit -- the property the
+    reference's deterministic_cuda_kernels switch asks for (train.py:41-45).  The atomic form
+    (O2M_WGRAD_ATOMICS=1) differs in the last bits from run to run."""
+    from one_to_many_gan_amd import _hip as H
+
+    assert not H.WGRAD_ATOMICS
+    torch.manual_seed(2)
+    B, S, Ci, Co = 16, 64, 256, 256
+    x = torch.randn(B, S, S, Ci, device="cuda").to(dt)
+    g = torch.randn(B, S, S, Co, device="cuda").to(dt)
+    outs = []
+    for _ in range(3):
+        dw = torch.zeros(Co, 3, 3, Ci, device="cuda")
+        H.conv2d_wgrad(x, g, dw, pad=1, pad_mode=H.PAD_REFLECT)
+        outs.append(dw)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    # accumulation semantics: a second launch ADDS to dw
+    H.conv2d_wgrad(x, g, outs[0], pad=1, pad_mode=H.PAD_REFLECT)
+    assert float((outs[0] - 2 * outs[1]).abs().max()) <= 1e-6 * float(outs[1].abs().max())
+
+
 def test_strided_conv_matches_torch():
     """o2m_conv_desc.stride (used by the space-to-depth form of the RGB tail conv)."""
     from one_to_many_gan_amd import _hip as H
