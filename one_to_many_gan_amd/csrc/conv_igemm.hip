@@ -121,9 +121,6 @@ __device__ __forceinline__ void stats_block_reduce(const float (&st)[16], float*
   }
 }
 
-// 16 zero bytes in global memory: the LDS-DMA source of every padding / out-of-problem slot
-__device__ __attribute__((aligned(16))) unsigned int o2m_zero16[4] = {0u, 0u, 0u, 0u};
-
 // WIDE: Ci % 64 == 0, so one 64-element stage lies inside ONE filter tap (tap-outer walk).
 // !WIDE: small Ci (image stems, Ci = 8..32): every 16-B chunk decodes its own tap.
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool IN_SCALE, bool WIDE>
@@ -257,10 +254,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
     const int n = n0 + dma_row(q);
     dwoff[j] = (DMA && n < Co) ? (unsigned)(n * K + dma_chk(q) * 8) * 2u : OOB_OFF;
   }
-  const unsigned short* Xg = static_cast<const unsigned short*>(d.x);
-  const unsigned short* Wg = static_cast<const unsigned short*>(d.w) + (size_t)b_first * d.w_batch_stride;
   typedef __attribute__((address_space(3))) void lds_void;
-  typedef __attribute__((address_space(1))) const void gbl_void;
 
   auto dma_tiles = [&](int kt, int stage) {
     if (!loader) return;
@@ -582,9 +576,6 @@ __device__ unsigned long long o2m_p8_stamps[2][8];
 #define P8_STAMP(i) do {} while (0)
 #endif
 
-// SPLIT: the second fill of a phase's region is issued in the middle of the MFMA segment instead of
-// the load segment (a fill costs the issuing wave ~165 cycles there: s_memtime stamps, r02 profiles).
-template <bool SPLIT>
 __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_desc d, const int m_begin, const int m_end) {
   using T = unsigned short;
   constexpr int BM = 256, BN = 256, NT = 512;
@@ -649,8 +640,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
   int a_ky[2] = {0, 0}, a_kx[2] = {0, 0}, a_cb[2] = {0, 0}, a_buf[2] = {0, 0};
   int b_kt[2] = {0, 0};
 
-  auto issue_a = [&](int r, int part) {  // part: 0 = whole region, 1 / 2 = its first / second fill only
-    if (part != 2 && a_cb[r] == 0) {  // first K-tile of a tap: gather offsets of this region's two fills
+  auto issue_a = [&](int r) {
+    if (a_cb[r] == 0) {  // first K-tile of a tap: gather offsets of this region's two fills
       const int dy = a_ky[r] - pad, dx = a_kx[r] - pad;
       const bool live = a_ky[r] < KH;  // past the reduction: zero fills, no traffic
 #pragma unroll
@@ -671,11 +662,9 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
     char* dst = smem + a_buf[r] * BUFB;
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
-      if (part == 1 + (1 - jj)) continue;
       const int j = 2 * r + jj;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void*)(dst + a_group(j) * 1024), 16, (int)aoff[j], a_cb[r] * 2, 0, 0);
     }
-    if (part == 1) return;
     a_buf[r] ^= 1;
     a_cb[r] += BK;
     if (a_cb[r] == Ci) {
@@ -683,17 +672,16 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
       if (++a_kx[r] == KW) { a_kx[r] = 0; ++a_ky[r]; }
     }
   };
-  auto issue_b = [&](int r, int part) {
+  auto issue_b = [&](int r) {
     const bool live = b_kt[r] < nk;
     char* dst = smem + (b_kt[r] & 1) * BUFB + OPB;
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
-      if (part == 1 + (1 - jj)) continue;
       const int j = 2 * r + jj;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void*)(dst + b_group(j) * 1024), 16,
                                                (int)(live ? dwoff[j] : OOB_OFF), b_kt[r] * (BK * 2), 0, 0);
     }
-    if (part != 1) ++b_kt[r];
+    ++b_kt[r];
   };
 
   // ---- fragments ------------------------------------------------------------------------------------
@@ -725,21 +713,18 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  auto multiply = [&](const bf16x8 (&bf)[2][2], int mh, int nh, auto&& midway) {
+  auto multiply = [&](const bf16x8 (&bf)[2][2], int mh, int nh) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           acc[mh * 4 + i][nh * 2 + j] =
               __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][ks], bf[j][ks], acc[mh * 4 + i][nh * 2 + j], 0, 0, 0);
-      if (ks == 0) midway();
-    }
     __builtin_amdgcn_s_setprio(0);
   };
-  auto nothing = [] {};
 #ifdef O2M_P8_STAMPS
   unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0;
 #endif
@@ -747,8 +732,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
 #define P8_WAIT_AND_SYNC()                                  \
   do {                                                      \
     P8_STAMP(0);                                            \
-    if constexpr (SPLIT) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");  \
-    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   \
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        \
     P8_STAMP(1);                                            \
     __builtin_amdgcn_s_barrier();                           \
     P8_STAMP(2);                                            \
@@ -761,12 +745,12 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
   } while (0)
 
   // ---- prologue: regions needed by phases -1 .. 4 -------------------------------------------------------
-  issue_b(0, 0);  // B0(0)
-  issue_a(0, 0);  // A0(0)
-  issue_b(1, 0);  // B1(0)
-  issue_a(1, 0);  // A1(0)
-  issue_b(0, 0);  // B0(1)
-  issue_a(0, 0);  // A0(1)
+  issue_b(0);  // B0(0)
+  issue_a(0);  // A0(0)
+  issue_b(1);  // B1(0)
+  issue_a(1);  // A1(0)
+  issue_b(0);  // B0(1)
+  issue_a(0);  // A0(1)
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // B0(0), A0(0) have landed for every wave
   __builtin_amdgcn_s_barrier();
   if (wrow == 1) __builtin_amdgcn_s_barrier();  // this wave row runs one barrier behind the other
@@ -781,33 +765,29 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
     // p1: A0 x B0
     read_a(cur, 0);
     P8_STAMP(5);
-    issue_b(1, SPLIT ? 1 : 0);  // B1(t+1)
+    issue_b(1);  // B1(t+1)
     P8_WAIT_AND_SYNC();
-    if constexpr (SPLIT) multiply(b0f, 0, 0, [&] { issue_b(1, 2); });
-    else multiply(b0f, 0, 0, nothing);
+    multiply(b0f, 0, 0);
     P8_CLOSE();
     // p2: A0 x B1
     read_b(b1f, cur, 1);
     P8_STAMP(5);
-    issue_a(1, SPLIT ? 1 : 0);  // A1(t+1)
+    issue_a(1);  // A1(t+1)
     P8_WAIT_AND_SYNC();
-    if constexpr (SPLIT) multiply(b1f, 0, 1, [&] { issue_a(1, 2); });
-    else multiply(b1f, 0, 1, nothing);
+    multiply(b1f, 0, 1);
     P8_CLOSE();
     // p3: A1 x B1
     read_a(cur, 1);
     P8_STAMP(5);
-    issue_b(0, SPLIT ? 1 : 0);  // B0(t+2)
+    issue_b(0);  // B0(t+2)
     P8_WAIT_AND_SYNC();
-    if constexpr (SPLIT) multiply(b1f, 1, 1, [&] { issue_b(0, 2); });
-    else multiply(b1f, 1, 1, nothing);
+    multiply(b1f, 1, 1);
     P8_CLOSE();
     // p4: A1 x B0, then the next K-tile's B0 fragments (landed: waited for at the end of p3)
     P8_STAMP(5);
-    issue_a(0, SPLIT ? 1 : 0);  // A0(t+2)
+    issue_a(0);  // A0(t+2)
     P8_WAIT_AND_SYNC();
-    if constexpr (SPLIT) multiply(b0f, 1, 0, [&] { issue_a(0, 2); });
-    else multiply(b0f, 1, 0, nothing);
+    multiply(b0f, 1, 0);
     read_b(b0f, cur ^ 1, 0);
     P8_CLOSE();
   }
@@ -887,281 +867,14 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
   }
 }
 
-int launch_p8(const o2m_conv_desc& d, hipStream_t s, int variant, long m_begin, long m_end) {
+int launch_p8(const o2m_conv_desc& d, hipStream_t s, long m_begin, long m_end) {
   constexpr int lds_main = 2 * 65536, lds_epi = 128 * (256 + 4) * 4;
   constexpr int lds = lds_main > lds_epi ? lds_main : lds_epi;
   const long tiles = tiles_rows<256, 256>(d, m_end - m_begin);
   if (tiles <= 0 || tiles > 0x7fffffffL) return O2M_ERR_BAD_ARG;
-  auto kern = variant == 2 ? conv_igemm_p8_kernel<true> : conv_igemm_p8_kernel<false>;
+  auto kern = conv_igemm_p8_kernel;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), lds, s, d, (int)m_begin, (int)m_end);
-  O2M_LAUNCH_CHECK();
-  return 0;
-}
-
-// =============================================================================================
-// Wave-specialised variant (bf16, Ci % 64 == 0, no in_scale): 8 waves = 4 LOADER waves + 4
-// CONSUMER waves, one of each per SIMD.  Measured on the symmetric kernel above (s_memtime
-// stamps): a wave pays ~125 issue cycles per LDS-DMA fill and cannot issue MFMAs meanwhile,
-// and the two waves of a SIMD then queue behind each other for the matrix pipe.  Here the
-// loaders only compute gather addresses and issue global_load_lds_dwordx4 for stage t+1
-// while the consumers -- alone on their SIMD's matrix pipe -- read fragments and multiply
-// stage t.  One s_barrier per stage hands the buffers over.  Tile 256 x 128 x 64: consumers
-// are 2 x 2, each 128 x 64 (128 accumulator VGPRs, inside the 256-VGPR budget both roles share).
-// =============================================================================================
-template <int BM, int BN>
-__global__ __launch_bounds__(512, 2) void conv_igemm_ws_kernel(const o2m_conv_desc d) {
-  using T = unsigned short;
-  constexpr int NT = 512, NLOAD = 4;
-  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
-  constexpr int FA = BM / 8 / NLOAD, FB = BN / 8 / NLOAD;  // fills per loader wave per stage
-  constexpr int NSTG = 3;  // LDS ring: the loaders run two stages ahead of the consumers
-  static_assert(FA + FB == 12, "the counted s_waitcnt below assumes 12 fills per stage");
-  constexpr int CWM = 2, CWN = 2, WM = BM / CWM, WN = BN / CWN, TM = WM / 32, TN = WN / 32;
-  static_assert(BM % (8 * NLOAD) == 0 && BN % (8 * NLOAD) == 0 && WM % 32 == 0 && WN % 32 == 0, "tile");
-
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int H = d.H, W = d.W, Ci = d.Ci, Co = d.Co, KH = d.KH, KW = d.KW, pad = d.pad;
-  const int Ho = H + 2 * pad - KH + 1, Wo = W + 2 * pad - KW + 1;
-  const int HoWo = Ho * Wo;
-  const int M = d.B * HoWo;
-  const int K = KH * KW * Ci;
-  const int nk = K / BK;
-  const bool reflect = d.pad_mode == O2M_PAD_REFLECT;
-
-  const int tiles_n = (Co + BN - 1) / BN;
-  const int tile = xcd_tile_order(blockIdx.x, gridDim.x);
-  const int m0 = (tile / tiles_n) * BM;
-  const int n0 = (tile % tiles_n) * BN;
-  const int b_first = m0 / HoWo;
-  const bool b_uniform = (min(m0 + BM, M) - 1) / HoWo == b_first;
-
-  const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const bool is_loader = wave < NLOAD;
-  typedef __attribute__((address_space(3))) void lds_void;
-  typedef __attribute__((address_space(1))) const void gbl_void;
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  if (is_loader) {
-    // ---- loader: lane l of fill q owns linear 16-B slot 64q + l of the tile ----------------
-    auto slot_row = [&](int q) {
-      const int pr = 4 * q + (lane >> 4);
-      return 2 * pr + (((lane & 15) ^ (pr & 15)) >> 3);
-    };
-    auto slot_chk = [&](int q) {
-      const int pr = 4 * q + (lane >> 4);
-      return ((lane & 15) ^ (pr & 15)) & 7;
-    };
-    int pix[FA], ryx[FA];
-#pragma unroll
-    for (int j = 0; j < FA; ++j) {
-      const int m = m0 + slot_row(wave * FA + j);
-      if (m < M) {
-        const int b = m / HoWo, rem = m - b * HoWo;
-        const int oy = rem / Wo, ox = rem - oy * Wo;
-        pix[j] = (b * H + oy) * W + ox;
-        ryx[j] = (oy << 16) | ox;
-      } else {
-        pix[j] = -1;
-        ryx[j] = 0;
-      }
-    }
-    int woff[FB];
-#pragma unroll
-    for (int j = 0; j < FB; ++j) {
-      const int q = wave * FB + j;
-      const int n = n0 + slot_row(q);
-      woff[j] = n < Co ? n * K + slot_chk(q) * 8 : -1;
-    }
-    const T* Xg = static_cast<const T*>(d.x);
-    const T* Wg = static_cast<const T*>(d.w) + (size_t)b_first * d.w_batch_stride;
-    unsigned aoff[FA];
-    int cur_tap = -1;
-
-    auto fill = [&](int kt, int stage) {
-      const int k0 = kt * BK;
-      const int tap = k0 / Ci;
-      const int cbase = k0 - tap * Ci;
-      if (tap != cur_tap) {
-        cur_tap = tap;
-        const int dy = tap / KW - pad, dx = tap - (tap / KW) * KW - pad;
-#pragma unroll
-        for (int j = 0; j < FA; ++j) {
-          const int oy = ryx[j] >> 16, ox = ryx[j] & 0xffff;
-          int iy = oy + dy, ix = ox + dx;
-          bool ok = pix[j] >= 0;
-          if (reflect) {
-            iy = iy < 0 ? -iy : (iy >= H ? 2 * H - 2 - iy : iy);
-            ix = ix < 0 ? -ix : (ix >= W ? 2 * W - 2 - ix : ix);
-          } else {
-            ok = ok && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-          }
-          aoff[j] = ok ? (unsigned)((pix[j] + (iy - oy) * W + (ix - ox)) * Ci + slot_chk(wave * FA + j) * 8) * 2
-                       : OOB_OFF;
-        }
-      }
-      char* a_dst = smem + stage * STAGE_BYTES + wave * FA * 1024;
-      char* b_dst = smem + stage * STAGE_BYTES + A_BYTES + wave * FB * 1024;
-#pragma unroll
-      for (int j = 0; j < FA; ++j) {
-        const void* src = aoff[j] != OOB_OFF
-                              ? static_cast<const void*>(reinterpret_cast<const char*>(Xg) + aoff[j] + (unsigned)cbase * 2)
-                              : static_cast<const void*>(o2m_zero16);
-        __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(a_dst + j * 1024), 16, 0, 0);
-      }
-#pragma unroll
-      for (int j = 0; j < FB; ++j) {
-        const void* src = woff[j] >= 0 ? static_cast<const void*>(Wg + woff[j] + k0)
-                                       : static_cast<const void*>(o2m_zero16);
-        __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(b_dst + j * 1024), 16, 0, 0);
-      }
-    };
-
-    // Raw s_barrier + COUNTED vmcnt: __syncthreads() would drain every fill in flight.  After
-    // issuing stage t+2, "vmcnt(12)" = all but the 12 youngest fills have landed = stage t+1 is
-    // complete when this wave arrives at the barrier that hands it to the consumers.
-    fill(0, 0);
-    if (nk > 1) {
-      fill(1, 1);
-      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    for (int kt = 0; kt < nk; ++kt) {
-      if (kt + 2 < nk) {
-        fill(kt + 2, (kt + 2) % NSTG);  // that buffer was last read in iteration kt-1
-        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      __builtin_amdgcn_s_barrier();
-    }
-  } else {
-    // ---- consumer ----------------------------------------------------------------------------
-    const int cw = wave - NLOAD;
-    const int wm = (cw / CWN) * WM, wn = (cw % CWN) * WN;
-    const int lr = lane & 31, lh = lane >> 5;
-    int fa[TM], fb[TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) fa[i] = tile_off(wm + i * 32 + lr, lh);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) fb[j] = tile_off(wn + j * 32 + lr, lh);
-
-    __builtin_amdgcn_s_barrier();  // stage 0 has landed
-    int stg = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-      const char* a_t = smem + stg * STAGE_BYTES;
-      const char* b_t = a_t + A_BYTES;
-      // fragments double-buffered in registers: the reads of k-step ks+1 are in flight while the
-      // MFMAs of k-step ks run (this wave is alone on its SIMD's matrix pipe)
-      bf16x8 af[2][TM], bf[2][TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const bf16x8*>(a_t + fa[i]);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const bf16x8*>(b_t + fb[j]);
-#pragma unroll
-      for (int ks = 0; ks < BK / 16; ++ks) {
-        if (ks + 1 < BK / 16) {
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-            af[(ks + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(a_t + (fa[i] ^ ((ks + 1) << 5)));
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            bf[(ks + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(b_t + (fb[j] ^ ((ks + 1) << 5)));
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bf[ks & 1][j], acc[i][j], 0, 0, 0);
-      }
-      stg = stg + 1 == NSTG ? 0 : stg + 1;
-      // all fragment reads of this stage were consumed by the MFMAs above (lgkmcnt drained)
-      __builtin_amdgcn_s_barrier();  // this stage may be overwritten; the next one has landed
-    }
-    __builtin_amdgcn_s_barrier();  // pairs with the loaders' epilogue entry below
-  }
-  if (is_loader) __builtin_amdgcn_s_barrier();  // all DMA writes done before LDS is reused
-
-  // ---- epilogue (all 8 waves store; the 4 consumers hold the tile) -----------------------------
-  constexpr int CSTR = BN + 4;
-  float* csm = reinterpret_cast<float*>(smem);
-  T* __restrict__ Y = static_cast<T*>(d.y);
-  const T* __restrict__ R = static_cast<const T*>(d.residual);
-  constexpr int VPR = BN / 8;
-  const int act = d.act;
-#pragma unroll 1
-  for (int pass = 0; pass < CWM; ++pass) {
-    if (!is_loader && (wave - NLOAD) / CWN == pass) {
-      const int cw = wave - NLOAD;
-      const int wn = (cw % CWN) * WN;
-      const int lr = lane & 31, lh = lane >> 5;
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            csm[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * CSTR + wn + j * 32 + lr] = acc[i][j][r];
-    }
-    __syncthreads();
-    const int mbase = m0 + pass * WM;
-#pragma unroll 1
-    for (int v = tid; v < WM * VPR; v += NT) {
-      const int row = v / VPR, c8 = v - row * VPR;
-      const int m = mbase + row, n = n0 + c8 * 8;
-      if (m >= M || n >= Co) continue;
-      const f32x4 a = *reinterpret_cast<const f32x4*>(csm + row * CSTR + c8 * 8);
-      const f32x4 b = *reinterpret_cast<const f32x4*>(csm + row * CSTR + c8 * 8 + 4);
-      float o[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-      if (d.out_scale) {
-        const float* sp = d.out_scale + (size_t)(b_uniform ? b_first : m / HoWo) * Co + n;
-        const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 4);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { o[q] *= s0[q]; o[4 + q] *= s1[q]; }
-      }
-      if (d.bias) {
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(d.bias + n), b1 = *reinterpret_cast<const f32x4*>(d.bias + n + 4);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { o[q] += b0[q]; o[4 + q] += b1[q]; }
-      }
-      if (act != O2M_ACT_NONE) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) o[q] = act_fwd(o[q], act);
-      }
-      const size_t off = (size_t)m * Co + n;
-      if (R) {
-        float rv[8];
-        load8(R + off, rv);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) o[q] += rv[q];
-      }
-      store8(Y + off, o);
-    }
-    if (pass + 1 < CWM) __syncthreads();
-  }
-}
-
-template <int BM, int BN>
-int launch_ws(const o2m_conv_desc& d, hipStream_t s) {
-  constexpr int lds_main = 3 * (BM + BN) * BK * 2;
-  constexpr int lds_epi = (BM / 2) * (BN + 4) * 4;
-  constexpr int lds = lds_main > lds_epi ? lds_main : lds_epi;
-  const long tiles = tiles_for<BM, BN>(d);
-  if (tiles <= 0 || tiles > 0x7fffffffL) return O2M_ERR_BAD_ARG;
-  auto kern = conv_igemm_ws_kernel<BM, BN>;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), lds, s, d);
   O2M_LAUNCH_CHECK();
   return 0;
 }
@@ -1194,16 +907,6 @@ constexpr long kFillBlocks = 256;  // one block per CU
 
 template <typename T>
 int launch_dtype(const o2m_conv_desc& d, hipStream_t s) {
-  if constexpr (sizeof(T) == 2) {
-    // Opt-in (O2M_IGEMM_WS=1): the wave-specialised variant.  Same-box A/B on the hot layers:
-    // 256->256 @64^2 727 vs 846 TF/s (its 256x128 tile re-reads A for the second N tile),
-    // 256->128 @128^2 759 vs 724.  Both variants end up at ~8.4 TB/s of L2->LDS ingest with a
-    // ~76% L2 hit rate at a ~1.65 GHz loaded clock, i.e. memory-side bound, so it is off.
-    static const int ws_mode = [] { const char* e = getenv("O2M_IGEMM_WS"); return e ? atoi(e) : 0; }();
-    if (ws_mode && !d.in_scale && d.stride <= 1 && d.Ci % BK == 0 && d.Co >= 128 &&
-        tiles_for<256, 128>(d) >= kFillBlocks)
-      return launch_ws<256, 128>(d, s);
-  }
   // big 8-wave tiles when they still give every CU a block; otherwise the 4-wave 128-wide
   // tiles (small-M layers of the discriminator) so the chip stays filled
   if (d.Co > 128) {
@@ -1221,11 +924,11 @@ int launch_dtype(const o2m_conv_desc& d, hipStream_t s) {
         if (split_tail && tiles > kFillBlocks && tail > 0 && tail <= kFillBlocks / 4 && (tiles - tail) % tn == 0 &&
             !d.stats) {
           const long m_split = (tiles - tail) / tn * 256;
-          const int rc = launch_p8(d, s, p8, 0, m_split);
+          const int rc = launch_p8(d, s, 0, m_split);
           if (rc) return rc;
           return launch_cfg<T, 128, 128, 2, 2>(d, s, m_split, rows);
         }
-        return launch_p8(d, s, p8, 0, rows);
+        return launch_p8(d, s, 0, rows);
       }
     }
     if (tiles_for<256, 256>(d) >= kFillBlocks) return launch_cfg<T, 256, 256, 2, 4>(d, s);

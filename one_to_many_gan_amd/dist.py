@@ -59,12 +59,12 @@ class BucketReducer:
         from . import ops
 
         for p in params:
-            if p.dim() == 4:
-                # conv filters: their gradient is written by ops._finalize_layer (kernel-layout
-                # accumulators), not by autograd's AccumulateGrad -- whose post-accumulate hook can
-                # still fire for them, earlier, and must not count
-                ops.GRAD_READY_HOOKS[p] = self._on_grad
-            else:
+            # conv filters: their gradient is written by ops._finalize_layer (kernel-layout
+            # accumulators), not by autograd's AccumulateGrad -- whose post-accumulate hook can
+            # still fire for them, earlier, and must not count.  to_style parameters may take either
+            # route (style_bwd adds into .grad directly when it can): both report here, once.
+            ops.GRAD_READY_HOOKS[p] = self._on_grad
+            if p.dim() != 4:
                 p.register_post_accumulate_grad_hook(self._on_grad)
 
     def _reset(self):

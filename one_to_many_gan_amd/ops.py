@@ -263,10 +263,10 @@ _DEFER_WGRAD = _os.environ.get("O2M_DEFER_WGRAD", "0") == "1"
 # stream, ordered by events, so they overlap the neighbouring convolution kernels.
 _SIDE_STREAM = _os.environ.get("O2M_SIDE_STREAM", "1") == "1"
 _SIDE: dict = {}
-# O2M_DIRECT_STYLE_GRADS=1: the style-gradient kernel adds the to_style gradients straight into the
-# parameters' .grad (no autograd additions for the five uses of a decoder layer per step).  Saves
-# ~100 tiny launches but measured no faster (56.4 vs 55.4 ms/step, same box), so it is off.
-_DIRECT_STYLE_GRADS = _os.environ.get("O2M_DIRECT_STYLE_GRADS", "0") == "1"
+# O2M_DIRECT_STYLE_GRADS=1 (default): the style-gradient kernel adds the to_style gradients straight
+# into the parameters' .grad when those are the fp32 slices of a FusedAdam bucket (no autograd
+# additions for the five uses of a decoder layer per step: ~100 tiny launches less).
+_DIRECT_STYLE_GRADS = _os.environ.get("O2M_DIRECT_STYLE_GRADS", "1") == "1"
 
 
 # O2M_WGRAD_STREAM=1: the weight-gradient reductions are off the critical path of backward (only
@@ -357,9 +357,12 @@ def _finalize_layer(prep):
         grad.add_(tmp.to(grad.dtype))
     else:
         H.wgrad_finalize(prep.dw_acc, prep.gq_acc, prep.get()[3], grad, prep.co, prep.ci, prep.c)
-    hook = GRAD_READY_HOOKS.get(w)
-    if hook is not None:
-        hook(w)
+    # the to_style parameters whose gradients style_bwd added straight into .grad never pass through
+    # autograd's AccumulateGrad: they are complete when the layer's last use has been reduced, too
+    for p in (w, *getattr(prep, "direct_style", ())):
+        hook = GRAD_READY_HOOKS.get(p)
+        if hook is not None:
+            hook(p)
 
 
 def _finalize_weight_grads():
@@ -490,6 +493,7 @@ class _ConvFn(torch.autograd.Function):
             H.conv2d_fwd(x, w_f, y, in_scale=s, out_scale=d, bias=bias_p, residual=residual,
                          pad=pad, pad_mode=pad_mode, act=act)
         ctx.prep, ctx.pad, ctx.pad_mode, ctx.act = prep, pad, pad_mode, act
+        ctx.norm_follows = stats_eps is not None
         ctx.counted = prep.note_forward_use(ctx.needs_input_grad[1])
         ctx.ts_params = (ts_weight, ts_bias)
         ctx.has_bias, ctx.has_res = bias is not None, residual is not None
@@ -512,7 +516,7 @@ class _ConvFn(torch.autograd.Function):
         dev = g.device
 
         sums = dots = None
-        want_sums = act != H.ACT_NONE or d is not None or (ctx.has_bias and need_b)
+        want_sums = act != H.ACT_NONE or d is not None or (ctx.has_bias and need_b and not ctx.norm_follows)
         want_dots = s is not None and (need_x or need_s or (need_w and d is not None))
         if want_sums or want_dots:  # one zero-fill for both atomically accumulated tables
             ns, nd = (B * 2 * prep.cop if want_sums else 0), (B * cip if want_dots else 0)
@@ -527,7 +531,12 @@ class _ConvFn(torch.autograd.Function):
             gu = g
 
         g_bias = None
-        if ctx.has_bias and need_b:
+        if ctx.has_bias and need_b and ctx.norm_follows:
+            # A bias ahead of InstanceNorm is mathematically dead: the incoming gradient (InstanceNorm's
+            # backward) has zero mean over the pixels of every (sample, channel), so its sum is exactly 0
+            # -- the reference's value there is rounding noise.  No reduction pass.
+            g_bias = torch.zeros(prep.co, dtype=weight.dtype, device=dev)
+        elif ctx.has_bias and need_b:
             if act == H.ACT_NONE and d is None:  # reduce-only pass over g (one read, nothing stored)
                 H.act_bwd_reduce(g, None, None, None, None, sums, H.ACT_NONE)
             tot = sums[:, 0].sum(0)
@@ -566,6 +575,7 @@ class _ConvFn(torch.autograd.Function):
                 and p.grad.is_contiguous() and p.grad.device == dev for k, p in ((4, tsw), (5, tsb)))
             if direct:
                 g_tw, g_tb = tsw.grad, tsb.grad
+                prep.direct_style = (tsw, tsb)  # reported complete together with the filter (_finalize_layer)
             else:
                 g_tw = torch.empty((prep.ci, wd_), dtype=torch.float32, device=dev)
                 g_tb = torch.empty((prep.ci,), dtype=torch.float32, device=dev)

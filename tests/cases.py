@@ -25,6 +25,19 @@ from oracle.detweights import fill_state_dict
 _FP64 = {"on": False}
 
 
+def host_threads() -> int:
+    """Threads for the CPU oracle: the cores this process may run on, at most 16 (a GPU box reports
+    every core of the host through os.cpu_count() but gives one GPU a 16-core share -- asking torch
+    for 256 threads there made the oracle several times slower)."""
+    import os
+
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
 def _maybe_double(fn):
     def wrapped(*a, **k):
         t = fn(*a, **k)
@@ -451,6 +464,7 @@ def run_case_shared_masks(name, product_namespace, oracle_namespace):
         return torch.where(m, t, 0.2 * t)
 
     om.ACT_OVERRIDE = replay
+    torch.set_num_threads(host_threads())
     try:
         with fp64_mode():
             want = run_case(name, oracle_namespace, "cpu")

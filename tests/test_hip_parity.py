@@ -16,7 +16,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.cases import CASES, run_case
+from tests.cases import CASES, host_threads, run_case
 from tests.namespaces import oracle_ns, product_ns
 
 pytestmark = pytest.mark.gpu
@@ -65,7 +65,7 @@ def _tolerance(name, key, precision):
 
 def _oracle(name):
     if name not in _oracle_cache:
-        torch.set_num_threads(os.cpu_count() or 1)
+        torch.set_num_threads(host_threads())
         _oracle_cache[name] = run_case(name, oracle_ns(), "cpu")
     return _oracle_cache[name]
 

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.cases import CASES, SLOW_CASES, run_case
+from tests.cases import CASES, SLOW_CASES, host_threads, run_case
 from tests.namespaces import oracle_ns
 
 # fp32 CPU vs fp32 CPU, same ATen kernels in a different call order: 1e-5 relative
@@ -22,7 +22,7 @@ def _rel(a, b):
 
 @pytest.mark.parametrize("name", [n for n in CASES])
 def test_oracle_matches_reference_fixture(name, golden_dir):
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(host_threads())
     gold = np.load(os.path.join(golden_dir, f"{name}.npz"))
     got = run_case(name, oracle_ns(), "cpu")
     assert set(got) == set(gold.files)
