@@ -34,6 +34,10 @@ extern "C" {
 
 #define O2M_BF16 0
 #define O2M_F32 1
+/* BASELINE config #5 (fp8 weight / activation path), o2m_conv2d_fwd only: x holds OCP fp8 bytes -- e4m3 for
+ * activations, e5m2 for gradients (the data-gradient call) --, w is always e4m3, y / residual are bf16. */
+#define O2M_FP8_E4M3 2
+#define O2M_BF8_E5M2 3
 
 #define O2M_ACT_NONE 0
 #define O2M_ACT_RELU 1
@@ -88,12 +92,27 @@ typedef struct {
                              o2m_instnorm_finalize turns the Ho*Wo/R partials of a sample into mean / rstd, so
                              the separate statistics pass over y (nn.InstanceNorm2d, builder.py:164,172,...;
                              blocks.py:23,27) disappears. */
+  const float* deq_scale; /* fp8 dtypes only (else NULL): DEVICE pointer to four floats, the `deq` pairs
+                             {1 / scale, amax} that o2m_quantize_fp8 wrote for x ([0], [1]) and for w ([2], [3]);
+                             the accumulator is multiplied by [0] * [2] before out_scale / bias / activation.
+                             Scales stay on the device: no host sync between quantisation and the convolution. */
 } o2m_conv_desc;
 int o2m_conv2d_fwd(const o2m_conv_desc* d, void* stream);
 /* Rows per InstanceNorm partial for this problem (the tile configuration o2m_conv2d_fwd would select),
  * or 0 when the epilogue cannot emit them (Ho*Wo not a multiple of the tile's row block: the odd-sized
  * discriminator maps -- the caller then runs o2m_instnorm_stats).  d->stats itself is not read. */
 int32_t o2m_conv2d_stats_rows(const o2m_conv_desc* d);
+
+/* Per-tensor fp8 quantisation (config #5).  Two launches per tensor, no host round trip, no atomics:
+ *   o2m_amax         : partial[k] = max |x| over block k's share, k < O2M_AMAX_PARTIALS (all written)
+ *   o2m_quantize_fp8 : amax = max_k partial[k];  scale = FMT_MAX / max(amax, 1e-12)  (448 for e4m3, 57344 for
+ *                      e5m2);  y[i] = fp8(x[i] * scale)  (round to nearest even, saturating);
+ *                      deq[0] = 1 / scale, deq[1] = amax
+ * x is `dtype` (O2M_BF16 / O2M_F32), y is `fmt` (O2M_FP8_E4M3 / O2M_BF8_E5M2) bytes, n % 8 == 0. */
+#define O2M_AMAX_PARTIALS 1024
+int o2m_amax(const void* x, float* amax, int64_t n, int32_t dtype, void* stream);
+int o2m_quantize_fp8(const void* x, const float* amax, void* y, float* deq, int64_t n, int32_t dtype,
+                     int32_t fmt, void* stream);
 
 /* Kernel-side forms of one equalised-LR filter (layers.py:12-24: W*c is recomputed on every
  * forward).  w is the parameter, fp32 [Co][Ci][KK] (KK = KH*KW).  Written:

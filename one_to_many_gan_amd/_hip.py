@@ -28,11 +28,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("O2M_HIP_LIB") or os.path.join(_HERE, "lib", "libo2m_hip.so")
 TORCH_LIB_PATH = os.path.join(_HERE, "lib", "libo2m_torch.so")
 
-BF16, F32 = 0, 1
+BF16, F32, FP8_E4M3, BF8_E5M2 = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 PAD_ZERO, PAD_REFLECT = 0, 1
 RED_L1, RED_SQ, RED_MOM = 0, 1, 2
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -42,7 +42,8 @@ class ConvDesc(C.Structure):
                 ("bias", _vp), ("residual", _vp),
                 ("B", _i32), ("H", _i32), ("W", _i32), ("Ci", _i32), ("Co", _i32), ("KH", _i32),
                 ("KW", _i32), ("pad", _i32), ("pad_mode", _i32), ("act", _i32), ("dtype", _i32),
-                ("w_batch_stride", _i32), ("stride", _i32), ("reserved", _i32 * 1), ("stats", _vp)]
+                ("w_batch_stride", _i32), ("stride", _i32), ("reserved", _i32 * 1), ("stats", _vp),
+                ("deq_scale", _vp)]
 
 
 class WgradDesc(C.Structure):
@@ -58,6 +59,8 @@ SIGNATURES = {
     "o2m_abi_version": (_i32, []),
     "o2m_conv2d_fwd": (_i32, [C.POINTER(ConvDesc), _vp]),
     "o2m_conv2d_stats_rows": (_i32, [C.POINTER(ConvDesc)]),
+    "o2m_amax": (_i32, [_vp, _vp, _i64, _i32, _vp]),
+    "o2m_quantize_fp8": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "o2m_instnorm_finalize": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),
     "o2m_conv2d_wgrad": (_i32, [C.POINTER(WgradDesc), _vp]),
     "o2m_conv2d_wgrad_slab_floats": (C.c_size_t, [C.POINTER(WgradDesc)]),
@@ -100,6 +103,8 @@ def _igemm_name(dt, co, scaled, m=1 << 30, k=1 << 30, ci=64):
     """Mirrors launch_dtype() in csrc/conv_igemm.hip, so the labels map one-to-one onto the
     kernels rocprofv3 reports."""
     t = "bf16" if dt == torch.bfloat16 else "f32x3"
+    if dt in (torch.float8_e4m3fn, torch.float8_e5m2):
+        return "conv_igemm_p8<fp8,256x256>"
 
     def tiles(bm, bn):
         return -(-m // bm) * -(-co // bn)
@@ -213,16 +218,32 @@ def check(err: int, what: str):
 
 
 def conv2d_fwd(x, w, y, *, in_scale=None, out_scale=None, bias=None, residual=None, pad, pad_mode, act,
-               per_sample_w=False, stride=1, stats=None):
-    """``stats``: fp32 workspace for the InstanceNorm partial sums of y (see o2m_conv_desc.stats)."""
+               per_sample_w=False, stride=1, stats=None, deq=None):
+    """``stats``: fp32 workspace for the InstanceNorm partial sums of y (see o2m_conv_desc.stats).
+    ``deq``: fp8 operands (x float8_e4m3fn / float8_e5m2, w float8_e4m3fn): device tensor of the two
+    dequantisation factors."""
     if PROFILE is None:
         return ops().conv2d_fwd(x, w, y, in_scale, out_scale, bias, residual, pad, pad_mode, act, per_sample_w, stride,
-                                stats)
+                                stats, deq)
     Co, KH, KW, Ci = w.shape[-4:]
     m = y.shape[0] * y.shape[1] * y.shape[2]
     _timed(_igemm_name(x.dtype, Co, in_scale is not None, m, KH * KW * Ci, Ci), 2.0 * m * Co * KH * KW * Ci, x,
            lambda: ops().conv2d_fwd(x, w, y, in_scale, out_scale, bias, residual, pad, pad_mode, act, per_sample_w,
-                                    stride, stats))
+                                    stride, stats, deq))
+
+
+AMAX_PARTIALS = 1024
+_AMAX_WS: dict = {}
+
+
+def quantize_fp8(x, y, deq):
+    """Per-tensor fp8 quantisation of ``x`` (bf16 / fp32) into ``y`` (float8_e4m3fn or float8_e5m2, same shape):
+    amax pass + scale-and-convert pass; ``deq`` (2 floats) receives {1 / scale, amax}."""
+    ws = _AMAX_WS.get(x.device)
+    if ws is None:
+        ws = _AMAX_WS[x.device] = torch.empty(AMAX_PARTIALS, dtype=torch.float32, device=x.device)
+    ops().amax(x, ws)
+    ops().quantize_fp8(x, ws, y, deq)
 
 
 def conv2d_stats_rows(x, w, y, *, pad, stride=1):

@@ -21,6 +21,7 @@
 //   staging and every product runs as hi*hi + hi*lo + lo*hi on the bf16 MFMA: ~2^-16
 //   relative error per product at 3/16 the cost of the fp32 MFMA.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -576,8 +577,17 @@ __device__ unsigned long long o2m_p8_stamps[2][8];
 #define P8_STAMP(i) do {} while (0)
 #endif
 
+// FMT: element format of the MFMA operands.  0 = bf16 (x, w, y bf16: v_mfma_f32_16x16x32_bf16).
+// 1 / 2 = BASELINE config #5, the fp8 path: x is OCP e4m3 (1) or e5m2 (2, gradients), w is e4m3, y / residual are
+// bf16, products on v_mfma_f32_16x16x32_{fp8,bf8}_fp8 with fp32 accumulation and one dequantisation factor
+// (d.deq_scale[0] * d.deq_scale[1], per-tensor scales of x and w) applied to the accumulator.  A 128-B LDS row then
+// holds 128 reduction elements: the same fills and LDS traffic feed twice the MFMA work of the bf16 form.
+template <int FMT>
 __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_desc d, const int m_begin, const int m_end) {
-  using T = unsigned short;
+  using T = unsigned short;               // y / residual element (bf16 in every format)
+  constexpr int ES = FMT ? 1 : 2;         // operand element size
+  constexpr int KT = 128 / ES;            // reduction elements per K-tile (one 128-B row)
+  constexpr int KS = FMT ? 4 : 2;         // MFMA k-steps (32 elements each) per K-tile
   constexpr int BM = 256, BN = 256, NT = 512;
   constexpr int OPB = 32768;   // one operand of one K-tile: 256 rows x 128 B
   constexpr int BUFB = 65536;  // A + B
@@ -588,7 +598,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
   const int HoWo = Ho * Wo;
   const int M = m_end;  // rows [m_begin, m_end) of the B * Ho * Wo output pixels (a launch may cover a slice)
   const int K = KH * KW * Ci;
-  const int nk = K / BK;
+  const int nk = K / KT;
   const bool reflect = d.pad_mode == O2M_PAD_REFLECT;
 
   const int tiles_n = (Co + BN - 1) / BN;
@@ -597,9 +607,9 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
   const int n0 = (tile % tiles_n) * BN;
   const int b_first = m0 / HoWo;
   const bool b_uniform = (min(m0 + BM, M) - 1) / HoWo == b_first;
-  const rsrc_t xr = make_rsrc(d.x, (unsigned)((size_t)d.B * H * W * Ci * 2));
-  const rsrc_t wr = make_rsrc(static_cast<const char*>(d.w) + (size_t)b_first * d.w_batch_stride * 2,
-                              (unsigned)((size_t)Co * K * 2));
+  const rsrc_t xr = make_rsrc(d.x, (unsigned)((size_t)d.B * H * W * Ci * ES));
+  const rsrc_t wr = make_rsrc(static_cast<const char*>(d.w) + (size_t)b_first * d.w_batch_stride * ES,
+                              (unsigned)((size_t)Co * K * ES));
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -633,7 +643,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
   for (int j = 0; j < 4; ++j) {
     const int q = b_group(j);
     const int n = n0 + slot_row(q);
-    dwoff[j] = n < Co ? (unsigned)(n * K + slot_chk(q) * 8) * 2u : OOB_OFF;
+    dwoff[j] = n < Co ? (unsigned)(n * K * ES + slot_chk(q) * 16) : OOB_OFF;
   }
   unsigned aoff[4];
   // per-region stream state (wave-uniform): next K-tile's tap (ky, kx), channel base, LDS buffer
@@ -656,17 +666,17 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
         } else {
           ok = ok && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
         }
-        aoff[j] = ok ? (unsigned)((pix[j] + (iy - oy) * W + (ix - ox)) * Ci + slot_chk(a_group(j)) * 8) * 2u : OOB_OFF;
+        aoff[j] = ok ? (unsigned)((pix[j] + (iy - oy) * W + (ix - ox)) * Ci * ES + slot_chk(a_group(j)) * 16) : OOB_OFF;
       }
     }
     char* dst = smem + a_buf[r] * BUFB;
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
       const int j = 2 * r + jj;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void*)(dst + a_group(j) * 1024), 16, (int)aoff[j], a_cb[r] * 2, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void*)(dst + a_group(j) * 1024), 16, (int)aoff[j], a_cb[r] * ES, 0, 0);
     }
     a_buf[r] ^= 1;
-    a_cb[r] += BK;
+    a_cb[r] += KT;
     if (a_cb[r] == Ci) {
       a_cb[r] = 0;
       if (++a_kx[r] == KW) { a_kx[r] = 0; ++a_ky[r]; }
@@ -679,32 +689,38 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
     for (int jj = 0; jj < 2; ++jj) {
       const int j = 2 * r + jj;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void*)(dst + b_group(j) * 1024), 16,
-                                               (int)(live ? dwoff[j] : OOB_OFF), b_kt[r] * (BK * 2), 0, 0);
+                                               (int)(live ? dwoff[j] : OOB_OFF), b_kt[r] * 128, 0, 0);
     }
     ++b_kt[r];
   };
 
   // ---- fragments ------------------------------------------------------------------------------------
-  // 16x16x32: lane l holds row l & 15, reduction elements 8 (l >> 4) + 32 ks .. +7 = chunk (l >> 4) + 4 ks.
-  // tile_off(R0 + 16 i + r, c + 4 ks) = (tile_off(R0 + r, c) ^ ((i & 1) << 7 | ks << 6)) + i * 2048  for R0 % 32 == 0
-  const int fa0 = tile_off(128 * wrow + (lane & 15), lane >> 4);
-  const int fb0 = tile_off(64 * wcol + (lane & 15), lane >> 4) + OPB;
-  bf16x8 af[4][2], b0f[2][2], b1f[2][2];
+  // 16x16x32: lane l holds row l & 15 and reduction elements 8 (l >> 4) + 32 ks .. +7 of the K-tile.
+  //   bf16: 16 bytes = chunk (l >> 4) + 4 ks            (ds_read_b128)
+  //   fp8 :  8 bytes = chunk (l >> 5) + 2 ks, half (l >> 4) & 1   (ds_read_b64; conflict-free: the 32 lanes of a
+  //          half-wave touch 16 different slots, two halves each)
+  // tile_off(R0 + 16 i + r, c ^ x) = (tile_off(R0 + r, c) ^ ((i & 1) << 7 | x << 4)) + i * 2048  for R0 % 32 == 0
+  using frag_t = std::conditional_t<FMT == 0, bf16x8, long>;
+  constexpr int KSH = FMT ? 5 : 6;  // k-step -> byte XOR: 2 chunks (fp8) or 4 chunks (bf16)
+  const int c0 = FMT ? (lane >> 5) : (lane >> 4), h0 = FMT ? ((lane >> 4) & 1) * 8 : 0;
+  const int fa0 = tile_off(128 * wrow + (lane & 15), c0) + h0;
+  const int fb0 = tile_off(64 * wcol + (lane & 15), c0) + h0 + OPB;
+  frag_t af[4][KS], b0f[2][KS], b1f[2][KS];
   auto read_a = [&](int buf, int mh) {
     const char* base = smem + buf * BUFB + mh * (64 * 128);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-        af[i][ks] = *reinterpret_cast<const bf16x8*>(base + ((fa0 ^ (((i & 1) << 7) | (ks << 6))) + i * 2048));
+      for (int ks = 0; ks < KS; ++ks)
+        af[i][ks] = *reinterpret_cast<const frag_t*>(base + ((fa0 ^ (((i & 1) << 7) | (ks << KSH))) + i * 2048));
   };
-  auto read_b = [&](bf16x8 (&bf)[2][2], int buf, int nh) {
+  auto read_b = [&](frag_t (&bf)[2][KS], int buf, int nh) {
     const char* base = smem + buf * BUFB + nh * (32 * 128);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-        bf[j][ks] = *reinterpret_cast<const bf16x8*>(base + ((fb0 ^ (((j & 1) << 7) | (ks << 6))) + j * 2048));
+      for (int ks = 0; ks < KS; ++ks)
+        bf[j][ks] = *reinterpret_cast<const frag_t*>(base + ((fb0 ^ (((j & 1) << 7) | (ks << KSH))) + j * 2048));
   };
 
   f32x4_t acc[8][4];
@@ -713,16 +729,19 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  auto multiply = [&](const bf16x8 (&bf)[2][2], int mh, int nh) {
+  auto multiply = [&](const frag_t (&bf)[2][KS], int mh, int nh) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+    for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[mh * 4 + i][nh * 2 + j] =
-              __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][ks], bf[j][ks], acc[mh * 4 + i][nh * 2 + j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) {
+          f32x4_t& c = acc[mh * 4 + i][nh * 2 + j];
+          if constexpr (FMT == 0) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][ks], bf[j][ks], c, 0, 0, 0);
+          else if constexpr (FMT == 1) c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(af[i][ks], bf[j][ks], c, 0, 0, 0);
+          else c = __builtin_amdgcn_mfma_f32_16x16x32_bf8_fp8(af[i][ks], bf[j][ks], c, 0, 0, 0);
+        }
     __builtin_amdgcn_s_setprio(0);
   };
 #ifdef O2M_P8_STAMPS
@@ -809,6 +828,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
   const T* __restrict__ R = static_cast<const T*>(d.residual);
   constexpr int VPR = BN / 8;
   const int act = d.act;
+  const float deq = (FMT != 0 && d.deq_scale) ? d.deq_scale[0] * d.deq_scale[2] : 1.f;  // {1/scale, amax} of x, of w
 #pragma unroll 1
   for (int pass = 0; pass < 2; ++pass) {
     if (pass == wrow) {
@@ -834,6 +854,10 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
       const f32x4 a = *reinterpret_cast<const f32x4*>(csm + row * CSTR + c8 * 8);
       const f32x4 b = *reinterpret_cast<const f32x4*>(csm + row * CSTR + c8 * 8 + 4);
       float o[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+      if constexpr (FMT != 0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] *= deq;
+      }
       if (d.out_scale) {
         const float* sp = d.out_scale + (size_t)(b_uniform ? b_first : m / HoWo) * Co + n;
         const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 4);
@@ -872,7 +896,8 @@ int launch_p8(const o2m_conv_desc& d, hipStream_t s, long m_begin, long m_end) {
   constexpr int lds = lds_main > lds_epi ? lds_main : lds_epi;
   const long tiles = tiles_rows<256, 256>(d, m_end - m_begin);
   if (tiles <= 0 || tiles > 0x7fffffffL) return O2M_ERR_BAD_ARG;
-  auto kern = conv_igemm_p8_kernel;
+  auto kern = d.dtype == O2M_FP8_E4M3 ? conv_igemm_p8_kernel<1>
+                                      : (d.dtype == O2M_BF8_E5M2 ? conv_igemm_p8_kernel<2> : conv_igemm_p8_kernel<0>);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), lds, s, d, (int)m_begin, (int)m_end);
   O2M_LAUNCH_CHECK();
@@ -970,10 +995,11 @@ extern "C" int o2m_debug_stamps(unsigned long long* out) {
 
 extern "C" int32_t o2m_conv2d_stats_rows(const o2m_conv_desc* d) {
   if (!d || d->B <= 0 || d->H <= 0 || d->W <= 0 || d->KH <= 0 || d->KW <= 0 || d->pad < 0) return 0;
-  if (d->dtype != O2M_BF16 && d->dtype != O2M_F32) return 0;
+  const bool f8 = d->dtype == O2M_FP8_E4M3 || d->dtype == O2M_BF8_E5M2;
+  if (d->dtype != O2M_BF16 && d->dtype != O2M_F32 && !f8) return 0;
   const int S = d->stride > 1 ? d->stride : 1;
   const long howo = (long)((d->H + 2 * d->pad - d->KH) / S + 1) * ((d->W + 2 * d->pad - d->KW) / S + 1);
-  const int r = stats_rows_for(*d);
+  const int r = f8 ? (d->stride > 1 || d->in_scale ? 0 : 128) : stats_rows_for(*d);  // fp8: always the p8 kernel
   return (r > 0 && howo > 0 && howo % r == 0) ? r : 0;
 }
 
@@ -984,7 +1010,8 @@ extern "C" int o2m_conv2d_fwd(const o2m_conv_desc* d, void* stream) {
   if (d->H + 2 * d->pad < d->KH || d->W + 2 * d->pad < d->KW) return O2M_ERR_BAD_ARG;
   if (d->pad_mode == O2M_PAD_REFLECT && (d->pad >= d->H || d->pad >= d->W)) return O2M_ERR_BAD_ARG;
   if (d->pad_mode != O2M_PAD_ZERO && d->pad_mode != O2M_PAD_REFLECT) return O2M_ERR_BAD_ARG;
-  const long esz = d->dtype == O2M_F32 ? 4 : 2;
+  const bool f8 = d->dtype == O2M_FP8_E4M3 || d->dtype == O2M_BF8_E5M2;
+  const long esz = d->dtype == O2M_F32 ? 4 : (f8 ? 1 : 2);
   // buffer descriptors address < 2 GiB per tensor (offset 0x80000000 marks "out of range")
   if ((long)d->B * d->H * d->W * (long)d->Ci * esz > 0x7fffffffL) return O2M_ERR_UNSUPPORTED;
   if (d->w_batch_stride < 0) return O2M_ERR_BAD_ARG;
@@ -998,6 +1025,12 @@ extern "C" int o2m_conv2d_fwd(const o2m_conv_desc* d, void* stream) {
   if (d->stats && (d->act != O2M_ACT_NONE || d->residual || d->out_scale || o2m_conv2d_stats_rows(d) == 0))
     return O2M_ERR_BAD_ARG;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (f8) {
+    // fp8 operands run on the phase-pipelined kernel only: a K-tile is 128 elements of one filter tap
+    if (d->in_scale || d->stride > 1 || !d->deq_scale) return O2M_ERR_BAD_ARG;
+    if (d->Ci % 128 != 0) return O2M_ERR_UNSUPPORTED;
+    return launch_p8(*d, s, 0, out_rows(*d));
+  }
   if (d->dtype == O2M_BF16) return launch_dtype<unsigned short>(*d, s);
   if (d->dtype == O2M_F32) return launch_dtype<float>(*d, s);
   return O2M_ERR_BAD_ARG;

@@ -604,6 +604,75 @@ __global__ void clear_kernel(float* p, long n) {
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) p[t] = 0.f;
 }
 
+// ---- per-tensor fp8 quantisation (config #5) ---------------------------------------------------
+// amax: O2M_AMAX_PARTIALS blocks, one plain store each (8192 atomicMax onto one word cost ~100 us: a
+// same-address atomic retires every ~12 ns chip-wide); the quantising kernel reduces the partials itself.
+template <typename T>
+__global__ __launch_bounds__(NT) void amax_kernel(const T* __restrict__ x, float* __restrict__ partial, long nvec) {
+  float m = 0.f;
+  for (long v = (long)blockIdx.x * NT + threadIdx.x; v < nvec; v += (long)gridDim.x * NT) {
+    float f[8];
+    load8(x + v * 8, f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m = fmaxf(m, fabsf(f[i]));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  __shared__ float red[NT / 64];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 1; i < NT / 64; ++i) m = fmaxf(m, red[i]);
+    partial[blockIdx.x] = m;
+  }
+}
+
+// y = fp8(x * scale), 8 values (one 8-byte store) per thread; thread 0 also publishes 1 / scale
+template <typename T, bool E5M2>
+__global__ __launch_bounds__(NT) void quantize_fp8_kernel(const T* __restrict__ x, const float* __restrict__ amax,
+                                                          unsigned long long* __restrict__ y, float* __restrict__ deq,
+                                                          long nvec) {
+  const float fmt_max = E5M2 ? 57344.f : 448.f;
+  // every block reduces the O2M_AMAX_PARTIALS partial maxima (4 KB out of L2) to the tensor's amax
+  __shared__ float red[NT / 64];
+  float m = 0.f;
+  for (int i = threadIdx.x; i < O2M_AMAX_PARTIALS; i += NT) m = fmaxf(m, amax[i]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = red[0];
+#pragma unroll
+  for (int i = 1; i < NT / 64; ++i) m = fmaxf(m, red[i]);
+  const float scale = fmt_max / fmaxf(m, 1e-12f);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    deq[0] = 1.f / scale;
+    deq[1] = m;  // the tensor's amax, for the caller's records (delayed scaling, tests)
+  }
+  for (long v = (long)blockIdx.x * NT + threadIdx.x; v < nvec; v += (long)gridDim.x * NT) {
+    float f[8];
+    load8(x + v * 8, f);
+    // v_cvt_pk_{fp8,bf8}_f32: two floats -> two bytes (RNE), into the low / high half of a dword
+    float c[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) c[i] = fminf(fmaxf(f[i] * scale, -fmt_max), fmt_max);
+    unsigned int w[2] = {0u, 0u};
+    if (E5M2) {
+      w[0] = __builtin_amdgcn_cvt_pk_bf8_f32(c[0], c[1], w[0], false);
+      w[0] = __builtin_amdgcn_cvt_pk_bf8_f32(c[2], c[3], w[0], true);
+      w[1] = __builtin_amdgcn_cvt_pk_bf8_f32(c[4], c[5], w[1], false);
+      w[1] = __builtin_amdgcn_cvt_pk_bf8_f32(c[6], c[7], w[1], true);
+    } else {
+      w[0] = __builtin_amdgcn_cvt_pk_fp8_f32(c[0], c[1], w[0], false);
+      w[0] = __builtin_amdgcn_cvt_pk_fp8_f32(c[2], c[3], w[0], true);
+      w[1] = __builtin_amdgcn_cvt_pk_fp8_f32(c[4], c[5], w[1], false);
+      w[1] = __builtin_amdgcn_cvt_pk_fp8_f32(c[6], c[7], w[1], true);
+    }
+    y[v] = (unsigned long long)w[0] | ((unsigned long long)w[1] << 32);
+  }
+}
+
 // ---- fused Adam ------------------------------------------------------------------------------
 __global__ __launch_bounds__(NT) void adam_kernel(float* p, const float* g, float* m, float* v,
                                                   const float* step, long n, float lr, float b1,
@@ -638,7 +707,33 @@ inline unsigned grid_for(long n, int per_block = NT) {
 
 extern "C" {
 
-int o2m_abi_version(void) { return 14; }
+int o2m_abi_version(void) { return 15; }
+
+int o2m_amax(const void* x, float* amax, int64_t n, int32_t dtype, void* stream) {
+  if (!x || !amax || n <= 0 || (n & 7)) return O2M_ERR_BAD_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const long nvec = n / 8;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(amax_kernel<T>, dim3(O2M_AMAX_PARTIALS), dim3(NT), 0, st, (const T*)x, amax, nvec));
+  O2M_LAUNCH_CHECK();
+  return 0;
+}
+
+int o2m_quantize_fp8(const void* x, const float* amax, void* y, float* deq, int64_t n, int32_t dtype, int32_t fmt,
+                     void* stream) {
+  if (!x || !amax || !y || !deq || n <= 0 || (n & 7)) return O2M_ERR_BAD_ARG;
+  if (fmt != O2M_FP8_E4M3 && fmt != O2M_BF8_E5M2) return O2M_ERR_BAD_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const long nvec = n / 8;
+  if (fmt == O2M_FP8_E4M3) {
+    DISPATCH_T(dtype, hipLaunchKernelGGL((quantize_fp8_kernel<T, false>), dim3(grid_for(nvec)), dim3(NT), 0, st,
+                                         (const T*)x, amax, (unsigned long long*)y, deq, nvec));
+  } else {
+    DISPATCH_T(dtype, hipLaunchKernelGGL((quantize_fp8_kernel<T, true>), dim3(grid_for(nvec)), dim3(NT), 0, st,
+                                         (const T*)x, amax, (unsigned long long*)y, deq, nvec));
+  }
+  O2M_LAUNCH_CHECK();
+  return 0;
+}
 
 int o2m_modulate_weights(const float* w32, const float* s, void* out, int32_t B, int32_t Co,
                          int32_t KK, int32_t Ci, int32_t dtype, void* stream) {

@@ -33,6 +33,9 @@ struct Launch {  // device guard + the stream PyTorch is enqueueing on for that 
                            : static_cast<void*>(c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream())) {}
 };
 
+inline bool is_fp8(const Tensor& t) {
+  return t.scalar_type() == at::kFloat8_e4m3fn || t.scalar_type() == at::kFloat8_e5m2;
+}
 inline int dtype_code(const Tensor& t, const char* what) {
   if (t.scalar_type() == at::kBFloat16) return O2M_BF16;
   if (t.scalar_type() == at::kFloat) return O2M_F32;
@@ -88,14 +91,23 @@ inline void done(int err, const char* op, bool meta) {
 
 void conv2d_fwd(const Tensor& x, const Tensor& w, Tensor& y, const OptT& in_scale, const OptT& out_scale,
                 const OptT& bias, const OptT& residual, int64_t pad, int64_t pad_mode, int64_t act,
-                bool per_sample_w, int64_t stride, const std::optional<Tensor>& stats) {
+                bool per_sample_w, int64_t stride, const std::optional<Tensor>& stats, const OptT& deq) {
   const char* op = "o2m::conv2d_fwd";
-  chk_f32(stats, op, "stats");
+  chk_f32(stats, op, "stats"); chk_f32(deq, op, "deq");
+  const bool f8 = is_fp8(x);
   chk(x, op, "x"); chk(w, op, "w"); chk(y, op, "y"); chk(residual, op, "residual");
   chk_f32(in_scale, op, "in_scale"); chk_f32(out_scale, op, "out_scale"); chk_f32(bias, op, "bias");
   TORCH_CHECK(x.dim() == 4 && y.dim() == 4 && w.dim() == (per_sample_w ? 5 : 4), op, ": x, y are NHWC; w is ",
               per_sample_w ? "[B][Co][KH][KW][Ci]" : "[Co][KH][KW][Ci]");
-  same_dtype(x, w, op, "x", "w"); same_dtype(x, y, op, "x", "y"); same_dtype(x, residual, op, "x", "residual");
+  if (f8) {  // config #5: fp8 operands, bf16 result
+    TORCH_CHECK(w.scalar_type() == at::kFloat8_e4m3fn && y.scalar_type() == at::kBFloat16, op,
+                ": fp8 activations need float8_e4m3fn filters and a bfloat16 output");
+    TORCH_CHECK(deq.has_value() && deq->numel() >= 4, op, ": fp8 operands need deq = {1/scale_x, amax_x, 1/scale_w, amax_w}");
+    same_dtype(y, residual, op, "y", "residual");
+  } else {
+    TORCH_CHECK(!deq.has_value(), op, ": deq is for fp8 operands only");
+    same_dtype(x, w, op, "x", "w"); same_dtype(x, y, op, "x", "y"); same_dtype(x, residual, op, "x", "residual");
+  }
   const int wd = per_sample_w ? 1 : 0;
   const int64_t Co = w.size(wd), KH = w.size(wd + 1), KW = w.size(wd + 2);
   TORCH_CHECK(w.size(wd + 3) == x.size(3), op, ": filter has ", w.size(wd + 3), " input channels, x has ", x.size(3));
@@ -113,7 +125,9 @@ void conv2d_fwd(const Tensor& x, const Tensor& w, Tensor& y, const OptT& in_scal
   d.in_scale = fptr(in_scale); d.out_scale = fptr(out_scale); d.bias = fptr(bias); d.residual = ptr(residual);
   d.B = i32(x.size(0), op); d.H = i32(x.size(1), op); d.W = i32(x.size(2), op); d.Ci = i32(x.size(3), op);
   d.Co = i32(Co, op); d.KH = i32(KH, op); d.KW = i32(KW, op); d.pad = i32(pad, op); d.pad_mode = i32(pad_mode, op);
-  d.act = i32(act, op); d.dtype = dtype_code(x, op);
+  d.act = i32(act, op);
+  d.dtype = f8 ? (x.scalar_type() == at::kFloat8_e4m3fn ? O2M_FP8_E4M3 : O2M_BF8_E5M2) : dtype_code(x, op);
+  d.deq_scale = fptr(deq);
   d.w_batch_stride = per_sample_w ? i32(Co * KH * KW * x.size(3), op) : 0;
   d.stride = i32(stride, op);
   if (stats.has_value()) {
@@ -131,7 +145,7 @@ int64_t conv2d_stats_rows(const Tensor& x, const Tensor& w, const Tensor& y, int
   o2m_conv_desc d{};
   d.B = i32(x.size(0), op); d.H = i32(x.size(1), op); d.W = i32(x.size(2), op); d.Ci = i32(x.size(3), op);
   d.Co = i32(w.size(0), op); d.KH = i32(w.size(1), op); d.KW = i32(w.size(2), op); d.pad = i32(pad, op);
-  d.dtype = dtype_code(x, op); d.stride = i32(stride, op);
+  d.dtype = is_fp8(x) ? O2M_FP8_E4M3 : dtype_code(x, op); d.stride = i32(stride, op);
   return o2m_conv2d_stats_rows(&d);
 }
 
@@ -205,6 +219,26 @@ void prepare_weights(const Tensor& w, Tensor& full, Tensor& w_f, Tensor& w_d, co
   O2M_CALL(op, w, o2m_prepare_weights(ptr<float>(w), ptr<float>(full), ptr(w_f), ptr(w_d), ptr<float>(q), ptr<float>(qt),
                                      i32(w.size(0), op), i32(w.size(1), op), i32(kk, op), i32(cop, op), i32(cip, op),
                                      static_cast<float>(c), dt_w_f, stream));
+}
+
+void amax(const Tensor& x, Tensor& out) {
+  const char* op = "o2m::amax";
+  chk(x, op, "x"); chk_f32(out, op, "amax");
+  TORCH_CHECK(out.numel() >= O2M_AMAX_PARTIALS && x.numel() % 8 == 0, op, ": amax workspace holds ", O2M_AMAX_PARTIALS,
+              " floats; x.numel() % 8 == 0");
+  const int dt_x = dtype_code(x, op);
+  O2M_CALL(op, x, o2m_amax(ptr(x), ptr<float>(out), x.numel(), dt_x, stream));
+}
+
+void quantize_fp8(const Tensor& x, const Tensor& amax_t, Tensor& y, Tensor& deq) {
+  const char* op = "o2m::quantize_fp8";
+  chk(x, op, "x"); chk_f32(amax_t, op, "amax"); chk(y, op, "y"); chk_f32(deq, op, "deq");
+  TORCH_CHECK(is_fp8(y) && y.numel() == x.numel() && x.numel() % 8 == 0, op, ": y is an fp8 tensor of x's size (multiple of 8)");
+  TORCH_CHECK(amax_t.numel() >= O2M_AMAX_PARTIALS && deq.numel() >= 2, op, ": amax workspace of ", O2M_AMAX_PARTIALS,
+              " floats, deq of 2 ({1 / scale, amax})");
+  const int dt_x = dtype_code(x, op);
+  const int fmt = y.scalar_type() == at::kFloat8_e4m3fn ? O2M_FP8_E4M3 : O2M_BF8_E5M2;
+  O2M_CALL(op, x, o2m_quantize_fp8(ptr(x), ptr<float>(amax_t), ptr(y), ptr<float>(deq), x.numel(), dt_x, fmt, stream));
 }
 
 void modulate_weights(const Tensor& w32, const Tensor& s, Tensor& out) {
@@ -468,7 +502,9 @@ TORCH_LIBRARY(o2m, m) {
   m.def("instnorm_ws_floats(int B, int P, int C) -> int", &instnorm_ws_floats);
   m.def("reduce_blocks(int n) -> int", &reduce_blocks);
   m.def("conv2d_fwd(Tensor x, Tensor w, Tensor(a!) y, Tensor? in_scale, Tensor? out_scale, Tensor? bias, Tensor? residual, "
-        "int pad, int pad_mode, int act, bool per_sample_w, int stride, Tensor(b!)? stats=None) -> ()");
+        "int pad, int pad_mode, int act, bool per_sample_w, int stride, Tensor(b!)? stats=None, Tensor? deq=None) -> ()");
+  m.def("amax(Tensor x, Tensor(a!) amax) -> ()");
+  m.def("quantize_fp8(Tensor x, Tensor amax, Tensor(a!) y, Tensor(b!) deq) -> ()");
   m.def("conv2d_stats_rows(Tensor x, Tensor w, Tensor y, int pad, int stride) -> int");
   m.def("instnorm_finalize(Tensor partial, Tensor(a!) mean_rstd, int P, int nchunks, float eps) -> ()");
   m.def("conv2d_wgrad(Tensor x, Tensor gy, Tensor(a!) dw, Tensor? in_scale, Tensor? gy_scale, int pad, int pad_mode, int splits, "
@@ -508,6 +544,8 @@ TORCH_LIBRARY(o2m, m) {
   m.impl("wgrad_finalize", &wgrad_finalize);      \
   m.impl("prepare_weights", &prepare_weights);    \
   m.impl("modulate_weights", &modulate_weights);  \
+  m.impl("amax", &amax);                          \
+  m.impl("quantize_fp8", &quantize_fp8);          \
   m.impl("style_fwd", &style_fwd);                \
   m.impl("style_bwd", &style_bwd);                \
   m.impl("act_bwd_reduce", &act_bwd_reduce);      \

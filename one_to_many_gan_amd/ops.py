@@ -23,10 +23,27 @@ _STATE = {"dtype": torch.bfloat16, "epoch": 0}
 
 def set_precision(precision: str) -> None:
     """"bf16": bf16 storage + bf16 MFMA (throughput mode, BASELINE config #2).
-    "fp32": fp32 storage + bf16x3 split MFMA (parity mode, <=1e-3 of the CPU reference)."""
-    if precision not in ("bf16", "fp32"):
+    "fp32": fp32 storage + bf16x3 split MFMA (parity mode, <=1e-3 of the CPU reference).
+    "fp8" : BASELINE config #5 -- bf16 storage; the forward and data-gradient products of every
+            convolution with a multiple of 128 input channels run on the fp8 MFMA: activations
+            quantised per tensor to OCP e4m3 (gradients: e5m2), filters to e4m3, scale = format
+            maximum / amax computed on the device, fp32 accumulation, bf16 results.  Weight
+            gradients, normalisation, losses and the fp32 master weights / Adam stay as in "bf16"."""
+    if precision not in ("bf16", "fp32", "fp8"):
         raise ValueError(precision)
-    _STATE["dtype"] = torch.bfloat16 if precision == "bf16" else torch.float32
+    _STATE["dtype"] = torch.float32 if precision == "fp32" else torch.bfloat16
+    _STATE["fp8"] = precision == "fp8"
+
+
+def fp8_enabled() -> bool:
+    return bool(_STATE.get("fp8", False))
+
+
+def _quantize(t: torch.Tensor, fmt: torch.dtype, deq_pair: torch.Tensor) -> torch.Tensor:
+    """Per-tensor fp8 copy of ``t``; ``deq_pair`` (2 floats on the device) receives {1 / scale, amax}."""
+    q = torch.empty(t.shape, dtype=fmt, device=t.device)
+    H.quantize_fp8(t, q, deq_pair)
+    return q
 
 
 def set_deterministic(flag: bool) -> None:
@@ -172,6 +189,25 @@ class PreparedWeight:
             if wst is not None:
                 torch.cuda.current_stream(device).wait_stream(wst)
             _finalize_layer(self)
+
+    def fp8_ok(self, data_grad: bool) -> bool:
+        """The fp8 kernel stages 128 reduction elements of ONE filter tap per K-tile."""
+        return fp8_enabled() and (self.cop if data_grad else self.cip) % 128 == 0
+
+    def get_fp8(self, data_grad: bool):
+        """e4m3 copy of the forward (or data-gradient) filter + the layer's 4-float dequantisation record
+        {1/scale_x, amax_x, 1/scale_w, amax_w}: the filter half is written here, once per weight version;
+        the activation half by the quantisation of every call's input (same stream, so ordered)."""
+        w_f, w_d = self.get()[:2]
+        key = (self._key, data_grad)
+        cache = getattr(self, "_fp8", None)
+        if cache is None:
+            cache = self._fp8 = {}
+        hit = cache.get(data_grad)
+        if hit is None or hit[0] != key:
+            rec = torch.zeros(4, dtype=torch.float32, device=w_f.device)
+            hit = cache[data_grad] = (key, _quantize(w_d if data_grad else w_f, torch.float8_e4m3fn, rec[2:4]), rec)
+        return hit[1], hit[2]
 
     def discard_partial(self):
         """Drop what an aborted backward pass left behind (see _enter_backward_pass)."""
@@ -471,24 +507,39 @@ class _ConvFn(torch.autograd.Function):
             # loader stays a plain copy, like the unmodulated conv
             w_b = torch.empty((B, *w_f.shape), dtype=x.dtype, device=x.device)
             H.modulate_weights(w32, s, w_b)
-            H.conv2d_fwd(x, w_b, y, out_scale=d, bias=bias_p, residual=residual, pad=pad,
-                         pad_mode=pad_mode, act=act, per_sample_w=True)
+            if prep.fp8_ok(False):  # config #5: e4m3 activations x e4m3 per-sample filters
+                rec = torch.empty(4, dtype=torch.float32, device=x.device)
+                x8, w8 = _quantize(x, torch.float8_e4m3fn, rec[0:2]), _quantize(w_b, torch.float8_e4m3fn, rec[2:4])
+                H.conv2d_fwd(x8, w8, y, out_scale=d, bias=bias_p, residual=residual, pad=pad,
+                             pad_mode=pad_mode, act=act, per_sample_w=True, deq=rec)
+            else:
+                H.conv2d_fwd(x, w_b, y, out_scale=d, bias=bias_p, residual=residual, pad=pad,
+                             pad_mode=pad_mode, act=act, per_sample_w=True)
         elif stats_eps is not None:
             # conv feeding an InstanceNorm: the epilogue emits the per-(sample, channel) partial sums
             # of y on its way out, so the statistics pass over y is not run (odd-sized maps: fallback)
             if s is not None or residual is not None or act != H.ACT_NONE:
                 raise RuntimeError("InstanceNorm statistics are emitted by plain convolutions only")
             mr = torch.empty((B, prep.cop, 2), dtype=torch.float32, device=x.device)
-            rows = H.conv2d_stats_rows(x, w_f, y, pad=pad) if _FUSED_IN_STATS else 0
+            xin, win, deq = x, w_f, None
+            if prep.fp8_ok(False):
+                win, deq = prep.get_fp8(False)
+                xin = _quantize(x, torch.float8_e4m3fn, deq[0:2])
+            rows = H.conv2d_stats_rows(xin, win, y, pad=pad) if _FUSED_IN_STATS else 0
+            part = None
             if rows:
                 nchunks = ho * wo // rows
                 part = torch.empty(B * nchunks * prep.cop * 2, dtype=torch.float32, device=x.device)
-                H.conv2d_fwd(x, w_f, y, bias=bias_p, pad=pad, pad_mode=pad_mode, act=act, stats=part)
+            H.conv2d_fwd(xin, win, y, bias=bias_p, pad=pad, pad_mode=pad_mode, act=act, stats=part, deq=deq)
+            if rows:
                 H.instnorm_finalize(part, mr, ho * wo, nchunks, stats_eps)
             else:
-                H.conv2d_fwd(x, w_f, y, bias=bias_p, pad=pad, pad_mode=pad_mode, act=act)
                 ws = torch.empty(H.instnorm_ws_floats(B, ho * wo, prep.cop), dtype=torch.float32, device=x.device)
                 H.instnorm_stats(y, ws, mr, stats_eps)
+        elif s is None and prep.fp8_ok(False):
+            w8, rec = prep.get_fp8(False)
+            H.conv2d_fwd(_quantize(x, torch.float8_e4m3fn, rec[0:2]), w8, y, out_scale=d, bias=bias_p,
+                         residual=residual, pad=pad, pad_mode=pad_mode, act=act, deq=rec)
         else:
             H.conv2d_fwd(x, w_f, y, in_scale=s, out_scale=d, bias=bias_p, residual=residual,
                          pad=pad, pad_mode=pad_mode, act=act)
@@ -548,7 +599,12 @@ class _ConvFn(torch.autograd.Function):
             hp = Hh + (2 * pad if pad_mode == H.PAD_REFLECT else 0)
             wp = Ww + (2 * pad if pad_mode == H.PAD_REFLECT else 0)
             gxp = torch.empty((B, hp, wp, cip), dtype=g.dtype, device=dev)
-            H.conv2d_fwd(gu, w_d, gxp, pad=kpad, pad_mode=H.PAD_ZERO, act=H.ACT_NONE)
+            if prep.fp8_ok(True):  # e5m2 gradients x e4m3 filter
+                w8, rec = prep.get_fp8(True)
+                H.conv2d_fwd(_quantize(gu, torch.float8_e5m2, rec[0:2]), w8, gxp, pad=kpad, pad_mode=H.PAD_ZERO,
+                             act=H.ACT_NONE, deq=rec)
+            else:
+                H.conv2d_fwd(gu, w_d, gxp, pad=kpad, pad_mode=H.PAD_ZERO, act=H.ACT_NONE)
             if s is not None or pad_mode == H.PAD_REFLECT:
                 g_x = torch.empty_like(x)
                 if s is not None:

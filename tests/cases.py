@@ -394,6 +394,9 @@ _reg("conv7_tail64", case_conv, cin=64, cout=3, k=7, pad=0, bias=True, n=2, h=16
 _reg("conv4_head", case_conv, cin=32, cout=1, k=4, pad=1, bias=True, n=2, h=9, w=9)
 _reg("modconv_p1", case_modconv, cin=16, cout=8, k=3, pad=1, wdim=6, n=3, h=10, w=12)
 _reg("modconv_reflect", case_modconv, cin=8, cout=8, k=3, pad=0, wdim=6, n=2, h=9, w=9, reflect=1)
+# 128-channel layers: the smallest shapes the fp8 path (config #5: Ci % 128 == 0) applies to
+_reg("conv3_c128", case_conv, cin=128, cout=128, k=3, pad=1, bias=True, n=2, h=12, w=12)
+_reg("modconv_c128", case_modconv, cin=128, cout=128, k=3, pad=0, wdim=6, n=2, h=16, w=16, reflect=1)
 _reg("blur_even", case_resample, kind="blur", n=2, c=8, h=8, w=10)
 _reg("up_even", case_resample, kind="up", n=2, c=8, h=8, w=6)
 _reg("up_odd", case_resample, kind="up", n=1, c=8, h=7, w=9)
@@ -402,6 +405,7 @@ _reg("down_odd", case_resample, kind="down", n=2, c=8, h=15, w=31)
 _reg("down_odd2", case_resample, kind="down", n=1, c=16, h=63, w=9)
 _reg("resblock", case_resblock, dim=8, n=2, h=9, w=10)
 _reg("modresblock", case_modresblock, dim=8, wdim=6, n=2, h=9, w=9)
+_reg("resblock_c128", case_resblock, dim=128, n=1, h=16, w=16)
 _reg("gen32", case_generator, nc=3, size=32, min_latent=8, n_res=3, start_filters=8, n=2)
 _reg("gen64_gray", case_generator, nc=1, size=64, min_latent=64, n_res=7, start_filters=16, n=1)
 # BASELINE config #4's topology (512x512: 3 downsamples, 512-channel latent) at a size the CPU finishes

@@ -194,6 +194,97 @@ def test_full_size_bf16_conv_matches_torch_fp32(case):
     assert worst < 2e-2, worst  # no single wrong tile hiding in the norm
 
 
+@pytest.mark.parametrize("fmt", [torch.float8_e4m3fn, torch.float8_e5m2], ids=["e4m3", "e5m2"])
+def test_fp8_quantisation_matches_torch(fmt):
+    """o2m_amax + o2m_quantize_fp8 (per-tensor scale FMT_MAX / amax, round to nearest even, OCP formats)
+    against torch's own float8 conversion of the same scaled values."""
+    from one_to_many_gan_amd import _hip as H
+
+    torch.manual_seed(4)
+    x = (torch.randn(4, 32, 32, 64, device="cuda") * 3).to(torch.bfloat16)
+    deq2 = torch.empty(2, device="cuda")
+    y = torch.empty(x.shape, dtype=fmt, device="cuda")
+    H.quantize_fp8(x, y, deq2)
+    deq, amax = deq2[0], deq2[1]
+    top = 448.0 if fmt == torch.float8_e4m3fn else 57344.0
+    assert float(amax) == float(x.float().abs().max())
+    assert abs(float(deq) * top / float(amax) - 1) < 1e-6
+    want = (x.float() * (top / amax)).clamp(-top, top).to(fmt)
+    same = (y.view(torch.uint8) == want.view(torch.uint8)).float().mean()
+    assert float(same) > 0.999, float(same)  # (a handful of exact ties may round the other way)
+    back = y.float() * deq
+    rel = float((back - x.float()).norm() / x.float().norm())
+    assert rel < (0.04 if fmt == torch.float8_e4m3fn else 0.08), rel  # 3 / 2 mantissa bits
+
+
+FP8_CONVS = [
+    # B, H, W, Ci, Co, k, pad, reflect, x format, features
+    (16, 64, 64, 256, 256, 3, 1, True, torch.float8_e4m3fn, "plain"),
+    (16, 64, 64, 256, 256, 3, 1, True, torch.float8_e4m3fn, "modulated"),
+    (16, 66, 66, 256, 256, 3, 2, False, torch.float8_e5m2, "plain"),      # data-gradient call: e5m2 gradients
+    (8, 64, 64, 512, 512, 3, 1, True, torch.float8_e4m3fn, "epilogue"),
+    (2, 16, 16, 128, 64, 3, 1, False, torch.float8_e4m3fn, "epilogue"),   # small: one ragged tile, Co < 256
+]
+
+
+@pytest.mark.parametrize("case", FP8_CONVS, ids=lambda c: "x".join(map(str, c[:7])) + "-" + c[9])
+def test_fp8_conv_matches_torch_on_the_quantised_operands(case):
+    """BASELINE config #5: the fp8 form of the phase-pipelined igemm kernel (e4m3 / e5m2 activations x e4m3
+    filters on v_mfma_f32_16x16x32_{fp8,bf8}_fp8, fp32 accumulate, device-side dequantisation factors, bf16 out).
+    Checked against torch's fp32 convolution of the SAME quantised operands, so only the summation order and
+    the bf16 rounding of y differ (3e-3); the quantisation error itself is what test_hip_parity's fp8 mode bounds."""
+    import torch.nn.functional as F
+
+    from one_to_many_gan_amd import _hip as H
+
+    B, Hh, Ww, Ci, Co, k, pad, reflect, xfmt, feat = case
+    torch.manual_seed(23)
+    dev = "cuda"
+    x = torch.randn(B, Hh, Ww, Ci, device=dev).to(torch.bfloat16)
+    nw = B if feat == "modulated" else 1
+    w = (torch.randn(nw, Co, k, k, Ci, device=dev) / (Ci * k * k) ** 0.5).to(torch.bfloat16)
+    dq = torch.empty(2, 2, device=dev)  # rows: {1 / scale, amax} of x and of w
+    x8 = torch.empty(x.shape, dtype=xfmt, device=dev)
+    w8 = torch.empty(w.shape, dtype=torch.float8_e4m3fn, device=dev)
+    H.quantize_fp8(x, x8, dq[0])
+    H.quantize_fp8(w, w8, dq[1])
+    deq = dq.view(-1)  # {1/scale_x, amax_x, 1/scale_w, amax_w}
+    ho, wo = Hh + 2 * pad - k + 1, Ww + 2 * pad - k + 1
+    y = torch.empty(B, ho, wo, Co, device=dev, dtype=torch.bfloat16)
+    kw = dict(pad=pad, pad_mode=H.PAD_REFLECT if reflect else H.PAD_ZERO, act=H.ACT_NONE, deq=deq)
+    scale = bias = res = None
+    if feat == "modulated":
+        scale = torch.rand(B, Co, device=dev) + 0.5
+        H.conv2d_fwd(x8, w8, y, out_scale=scale, per_sample_w=True, **kw)
+    elif feat == "epilogue":
+        bias = torch.randn(Co, device=dev)
+        res = torch.randn(B, ho, wo, Co, device=dev).to(torch.bfloat16)
+        kw["act"] = H.ACT_LRELU
+        H.conv2d_fwd(x8, w8[0], y, bias=bias, residual=res, **kw)
+    else:
+        H.conv2d_fwd(x8, w8[0], y, **kw)
+    xq, wq = x8.float() * deq[0], w8.float() * deq[2]
+    xin = xq.permute(0, 3, 1, 2)
+    xin = F.pad(xin, (pad,) * 4, mode="reflect") if reflect else F.pad(xin, (pad,) * 4)
+    if feat == "modulated":
+        ref = F.conv2d(xin.reshape(1, B * Ci, *xin.shape[2:]), wq.permute(0, 1, 4, 2, 3).reshape(B * Co, Ci, k, k),
+                       groups=B).view(B, Co, ho, wo) * scale.view(B, Co, 1, 1)
+    else:
+        ref = F.conv2d(xin, wq[0].permute(0, 3, 1, 2))
+    if feat == "epilogue":
+        ref = F.leaky_relu(ref + bias.view(1, -1, 1, 1), 0.2) + res.float().permute(0, 3, 1, 2)
+    ref = ref.permute(0, 2, 3, 1)
+    err = float((y.float() - ref).norm() / ref.norm())
+    assert err < 3e-3, err
+    assert float((y.float() - ref).abs().max() / ref.abs().max()) < 2e-2
+    # and the quantised conv stays within fp8's own error of the unquantised one
+    full = F.conv2d(F.pad(x.float().permute(0, 3, 1, 2), (pad,) * 4, mode="reflect" if reflect else "constant"),
+                    w[0].float().permute(0, 3, 1, 2)) if feat == "plain" else None
+    if full is not None:
+        qerr = float((y.float() - full.permute(0, 2, 3, 1)).norm() / full.norm())
+        assert qerr < 8e-2, qerr
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_rgb_tail_space_to_depth_path_is_self_adjoint(precision):
     """The 64 -> 3 7x7 reflect-padded tail conv runs as a stride-4 conv over 4x4 output blocks

@@ -11,7 +11,7 @@ from tests.cases import CASES, run_case
 from tests.namespaces import product_ns
 
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
-precs = ["fp32", "bf16"]
+precs = ["fp32", "bf16"]  # also "fp8" (config #5) via --prec=fp8
 for a in sys.argv[1:]:
     if a.startswith("--prec="):
         precs = a.split("=")[1].split(",")
