@@ -28,6 +28,7 @@
 namespace {
 
 constexpr int BK = 64;  // reduction elements per stage (one 128-B LDS row of bf16)
+constexpr long kFillBlocks = 256;  // one block per CU
 
 // Byte offset of 16-B slot (row, chunk) in a [rows][64] bf16 tile.  Two 128-B rows share a
 // 256-B bank row; XOR with (row>>1)&15 spreads each ds_read_b128 lane group (same chunk,
@@ -928,7 +929,6 @@ int launch_cfg(const o2m_conv_desc& d, hipStream_t s, long m_begin = 0, long m_e
   return 0;
 }
 
-constexpr long kFillBlocks = 256;  // one block per CU
 
 template <typename T>
 int launch_dtype(const o2m_conv_desc& d, hipStream_t s) {

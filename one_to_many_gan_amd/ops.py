@@ -35,6 +35,9 @@ def set_precision(precision: str) -> None:
     _STATE["fp8"] = precision == "fp8"
 
 
+FP8_EVERYWHERE = False  # tests: route every Ci % 128 == 0 convolution through the fp8 kernel, whatever its size
+
+
 def fp8_enabled() -> bool:
     return bool(_STATE.get("fp8", False))
 
@@ -190,9 +193,15 @@ class PreparedWeight:
                 torch.cuda.current_stream(device).wait_stream(wst)
             _finalize_layer(self)
 
-    def fp8_ok(self, data_grad: bool) -> bool:
-        """The fp8 kernel stages 128 reduction elements of ONE filter tap per K-tile."""
-        return fp8_enabled() and (self.cop if data_grad else self.cip) % 128 == 0
+    def fp8_ok(self, data_grad: bool, rows: int) -> bool:
+        """The fp8 kernel stages 128 reduction elements of ONE filter tap per K-tile and exists as the
+        256 x 256-tile phase-pipelined kernel only: by default it takes the layers that kernel would take
+        in bf16 (more than 128 output channels, >= 256 tiles); FP8_EVERYWHERE (parity tests) drops the
+        size condition so that small cases reach it too."""
+        k_ch, n_ch = (self.cop, self.cip) if data_grad else (self.cip, self.cop)
+        if not fp8_enabled() or k_ch % 128 != 0:
+            return False
+        return FP8_EVERYWHERE or (n_ch > 128 and -(-rows // 256) * -(-n_ch // 256) >= 256)
 
     def get_fp8(self, data_grad: bool):
         """e4m3 copy of the forward (or data-gradient) filter + the layer's 4-float dequantisation record
@@ -507,7 +516,7 @@ class _ConvFn(torch.autograd.Function):
             # loader stays a plain copy, like the unmodulated conv
             w_b = torch.empty((B, *w_f.shape), dtype=x.dtype, device=x.device)
             H.modulate_weights(w32, s, w_b)
-            if prep.fp8_ok(False):  # config #5: e4m3 activations x e4m3 per-sample filters
+            if prep.fp8_ok(False, B * ho * wo):  # config #5: e4m3 activations x e4m3 per-sample filters
                 rec = torch.empty(4, dtype=torch.float32, device=x.device)
                 x8, w8 = _quantize(x, torch.float8_e4m3fn, rec[0:2]), _quantize(w_b, torch.float8_e4m3fn, rec[2:4])
                 H.conv2d_fwd(x8, w8, y, out_scale=d, bias=bias_p, residual=residual, pad=pad,
@@ -522,7 +531,7 @@ class _ConvFn(torch.autograd.Function):
                 raise RuntimeError("InstanceNorm statistics are emitted by plain convolutions only")
             mr = torch.empty((B, prep.cop, 2), dtype=torch.float32, device=x.device)
             xin, win, deq = x, w_f, None
-            if prep.fp8_ok(False):
+            if prep.fp8_ok(False, B * ho * wo):
                 win, deq = prep.get_fp8(False)
                 xin = _quantize(x, torch.float8_e4m3fn, deq[0:2])
             rows = H.conv2d_stats_rows(xin, win, y, pad=pad) if _FUSED_IN_STATS else 0
@@ -536,7 +545,7 @@ class _ConvFn(torch.autograd.Function):
             else:
                 ws = torch.empty(H.instnorm_ws_floats(B, ho * wo, prep.cop), dtype=torch.float32, device=x.device)
                 H.instnorm_stats(y, ws, mr, stats_eps)
-        elif s is None and prep.fp8_ok(False):
+        elif s is None and prep.fp8_ok(False, B * ho * wo):
             w8, rec = prep.get_fp8(False)
             H.conv2d_fwd(_quantize(x, torch.float8_e4m3fn, rec[0:2]), w8, y, out_scale=d, bias=bias_p,
                          residual=residual, pad=pad, pad_mode=pad_mode, act=act, deq=rec)
@@ -599,7 +608,7 @@ class _ConvFn(torch.autograd.Function):
             hp = Hh + (2 * pad if pad_mode == H.PAD_REFLECT else 0)
             wp = Ww + (2 * pad if pad_mode == H.PAD_REFLECT else 0)
             gxp = torch.empty((B, hp, wp, cip), dtype=g.dtype, device=dev)
-            if prep.fp8_ok(True):  # e5m2 gradients x e4m3 filter
+            if prep.fp8_ok(True, B * hp * wp):  # e5m2 gradients x e4m3 filter
                 w8, rec = prep.get_fp8(True)
                 H.conv2d_fwd(_quantize(gu, torch.float8_e5m2, rec[0:2]), w8, gxp, pad=kpad, pad_mode=H.PAD_ZERO,
                              act=H.ACT_NONE, deq=rec)

@@ -37,7 +37,7 @@ class _OracleBlur(torch.nn.Module):
 
 
 def product_ns(precision="fp32"):
-    """HIP path.  ``precision``: "fp32" (bf16x3 split MFMA, parity mode) or "bf16"."""
+    """HIP path.  ``precision``: "fp32" (bf16x3 split MFMA, parity mode), "bf16", or "fp8" (config #5)."""
     import one_to_many_gan_amd as pk
     from one_to_many_gan_amd.core import training as pt
     from one_to_many_gan_amd.model import blocks as pb
@@ -46,6 +46,7 @@ def product_ns(precision="fp32"):
     from one_to_many_gan_amd.model import loss as plo
 
     pk.set_precision(precision)
+    pk.ops.FP8_EVERYWHERE = precision == "fp8"  # the parity cases are far below the sizes fp8 is used at by default
     return SimpleNamespace(
         name=f"hip-{precision}",
         conv=lambda cin, cout, k, pad, bias: pl.EqualisedConv2d(cin, cout, k, padding=pad, use_bias=bias),
