@@ -136,23 +136,24 @@ def oracle_namespace():
                            discriminator_step=ot.discriminator_step, generator_step=ot.generator_step)
 
 
-def kernel_profile(trainer, precision):
-    """One extra (untimed) step with a HIP-event pair around every MFMA conv launch, on the
-    stream the kernels are launched on.  Returns the dominant kernel's aggregate."""
+def kernel_profile(trainer, precision, steps=3):
+    """``steps`` extra (untimed) steps with the library's launch timing on: a HIP-event pair around every
+    MFMA conv KERNEL (inside the launch site, so a call that runs two kernels files them separately), on
+    the stream each kernel is launched on.  Returns the dominant kernel's per-step aggregate."""
     from one_to_many_gan_amd import _hip
 
-    _hip.PROFILE = []
-    trainer.step()
-    torch.cuda.synchronize()
-    records, _hip.PROFILE = _hip.PROFILE, None
-    agg = {}
-    for name, flops, e0, e1 in records:
-        a = agg.setdefault(name, [0, 0.0, 0.0])
-        a[0] += 1
-        a[1] += e0.elapsed_time(e1) * 1e-3
-        a[2] += flops
+    _hip.launch_timing(True)
+    try:
+        for _ in range(steps):
+            trainer.step()
+        torch.cuda.synchronize()
+        agg = {k: list(v) for k, v in _hip.launch_timing_read().items()}
+    finally:
+        _hip.launch_timing(False)
     if not agg:
         return None
+    for a in agg.values():  # per step
+        a[0], a[1], a[2] = a[0] / steps, a[1] / steps, a[2] / steps
     total_conv_s = sum(a[1] for a in agg.values())
     name, (n, secs, flops) = max(agg.items(), key=lambda kv: kv[1][1])
     achieved = flops / secs / 1e12
@@ -173,9 +174,9 @@ def kernel_profile(trainer, precision):
     return {
         "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
         "frac": round(achieved / peak, 4), "traffic": traffic,
-        "kernel": name, "launches_per_step": n, "avg_launch_us": round(secs / n * 1e6, 2),
+        "kernel": name, "launches_per_step": round(n, 1), "avg_launch_us": round(secs / n * 1e6, 2),
         "share_of_conv_time": round(secs / total_conv_s, 3),
-        "all_conv_kernels": {k: {"launches": v[0], "ms": round(v[1] * 1e3, 3),
+        "all_conv_kernels": {k: {"launches": round(v[0], 1), "ms": round(v[1] * 1e3, 3),
                                  "tflops": round(v[2] / v[1] / 1e12, 1)} for k, v in sorted(agg.items())},
     }
 

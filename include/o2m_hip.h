@@ -54,6 +54,27 @@ extern "C" {
 int o2m_abi_version(void);
 
 /* ------------------------------------------------------------------------------------
+ * Per-kernel launch timing for bench.py's roofline object (measurement only; the reference
+ * has no counterpart).  While enabled, every MFMA conv launch (igemm, its tail launch, wgrad,
+ * the wgrad slab sum) is bracketed by a HIP-event pair on ITS launch stream and filed under
+ * the kernel's name as rocprofv3 would resolve it, e.g. "conv_igemm_p8<bf16,256x256>",
+ * "conv_igemm<bf16,256x64,in_scale=0>", "conv_wgrad<bf16,co128xk128>", "wgrad_reduce".
+ *   o2m_launch_timing(1|0)   switch recording on / off; returns the previous state.
+ *   o2m_launch_timing_read   waits for the recorded events, sums them per kernel name into
+ *                            out[0..capacity) (launches, milliseconds, algorithmic flops of
+ *                            the rows each launch covered), clears the records and returns
+ *                            the number of kernels written (< 0: error).
+ * Costs two event records per launch while on; nothing but a flag test while off. */
+typedef struct o2m_launch_stat {
+  char kernel[64];
+  int32_t launches;
+  float ms;
+  double flops;
+} o2m_launch_stat;
+int32_t o2m_launch_timing(int32_t enable);
+int32_t o2m_launch_timing_read(o2m_launch_stat* out, int32_t capacity);
+
+/* ------------------------------------------------------------------------------------
  * Implicit-GEMM convolution on MFMA (v_mfma_f32_32x32x16_bf16), stride 1, dilation 1.
  *   y[b,oy,ox,o] = act( out_scale[b,o] * sum_{kh,kw,i} w[o,kh,kw,i] *
  *                        (in_scale[b,i] * xpad[b,oy+kh-pad,ox+kw-pad,i]) + bias[o] )

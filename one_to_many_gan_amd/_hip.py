@@ -32,7 +32,7 @@ BF16, F32, FP8_E4M3, BF8_E5M2 = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 PAD_ZERO, PAD_REFLECT = 0, 1
 RED_L1, RED_SQ, RED_MOM = 0, 1, 2
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -57,6 +57,8 @@ class WgradDesc(C.Structure):
 # name -> (restype, argtypes); mirrors include/o2m_hip.h one for one
 SIGNATURES = {
     "o2m_abi_version": (_i32, []),
+    "o2m_launch_timing": (_i32, [_i32]),
+    "o2m_launch_timing_read": (_i32, [_vp, _i32]),
     "o2m_conv2d_fwd": (_i32, [C.POINTER(ConvDesc), _vp]),
     "o2m_conv2d_stats_rows": (_i32, [C.POINTER(ConvDesc)]),
     "o2m_amax": (_i32, [_vp, _vp, _i64, _i32, _vp]),
@@ -92,60 +94,28 @@ SIGNATURES = {
 }
 
 _lib = None
-P8_ENABLED = os.environ.get("O2M_IGEMM_P8", "1") != "0"  # mirrors the switch in csrc/conv_igemm.hip
-
-# bench.py sets this to a list to time every MFMA conv launch with a HIP-event pair on the
-# launch stream: entries are (kernel_name, algorithmic_flops, start_event, end_event).
-PROFILE = None
 
 
-def _igemm_name(dt, co, scaled, m=1 << 30, k=1 << 30, ci=64):
-    """Mirrors launch_dtype() in csrc/conv_igemm.hip, so the labels map one-to-one onto the
-    kernels rocprofv3 reports."""
-    t = "bf16" if dt == torch.bfloat16 else "f32x3"
-    if dt in (torch.float8_e4m3fn, torch.float8_e5m2):
-        return "conv_igemm_p8<fp8,256x256>"
+class LaunchStat(C.Structure):
+    """o2m_launch_stat (include/o2m_hip.h)."""
 
-    def tiles(bm, bn):
-        return -(-m // bm) * -(-co // bn)
-
-    if co > 128:
-        if tiles(256, 256) >= 256 and dt == torch.bfloat16 and not scaled and ci % 64 == 0 and P8_ENABLED:
-            return "conv_igemm_p8<bf16,256x256>"
-        tile = "256x256" if tiles(256, 256) >= 256 else "128x128"
-    elif co > 64:
-        if k <= 1152 and tiles(256, 64) >= 512:
-            tile = "256x64"
-        else:
-            tile = "256x128" if tiles(256, 128) >= 256 else "128x128"
-    elif co > 32:
-        tile = "256x64" if tiles(256, 64) >= 256 else "128x64"
-    else:
-        tile = "256x32"
-    return f"conv_igemm<{t},{tile},in_scale={int(scaled)}>"
+    _fields_ = [("kernel", C.c_char * 64), ("launches", C.c_int32), ("ms", C.c_float), ("flops", C.c_double)]
 
 
-def _wgrad_name(dt, co, m=0, k=0):
-    """Mirrors launch_dtype() in csrc/conv_wgrad.hip."""
-    t = "bf16" if dt == torch.bfloat16 else "f32x3"
-    if co > 256 or (co > 128 and m >= 100000):
-        tile = "co256xk128"
-    elif 64 < co <= 128 and k % 256 == 0 and dt == torch.bfloat16:
-        tile = "co128xk256"
-    else:
-        tile = ("co128" if co > 64 else ("co64" if co > 32 else "co32")) + "xk128"
-    return f"conv_wgrad<{t},{tile}>"
+def launch_timing(enable: bool) -> bool:
+    """Switch the library's per-kernel launch timing (HIP-event pairs inside the launch sites, on the
+    launch stream) on or off; returns the previous state.  bench.py's roofline object uses it."""
+    return bool(lib().o2m_launch_timing(int(bool(enable))))
 
 
-def _timed(name, flops, tensor, launch):
-    if PROFILE is None:
-        return launch()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    st = torch.cuda.current_stream(tensor.device)
-    e0.record(st)
-    launch()
-    e1.record(st)
-    PROFILE.append((name, flops, e0, e1))
+def launch_timing_read(capacity: int = 64):
+    """{kernel name: (launches, seconds, algorithmic flops)} of the launches recorded since the last
+    read; waits for them to finish."""
+    table = (LaunchStat * capacity)()
+    n = lib().o2m_launch_timing_read(table, capacity)
+    if n < 0:
+        raise RuntimeError(f"o2m_launch_timing_read failed with code {n}")
+    return {table[i].kernel.decode(): (table[i].launches, table[i].ms * 1e-3, table[i].flops) for i in range(n)}
 
 
 def lib():
@@ -222,14 +192,8 @@ def conv2d_fwd(x, w, y, *, in_scale=None, out_scale=None, bias=None, residual=No
     """``stats``: fp32 workspace for the InstanceNorm partial sums of y (see o2m_conv_desc.stats).
     ``deq``: fp8 operands (x float8_e4m3fn / float8_e5m2, w float8_e4m3fn): device tensor of the two
     dequantisation factors."""
-    if PROFILE is None:
-        return ops().conv2d_fwd(x, w, y, in_scale, out_scale, bias, residual, pad, pad_mode, act, per_sample_w, stride,
-                                stats, deq)
-    Co, KH, KW, Ci = w.shape[-4:]
-    m = y.shape[0] * y.shape[1] * y.shape[2]
-    _timed(_igemm_name(x.dtype, Co, in_scale is not None, m, KH * KW * Ci, Ci), 2.0 * m * Co * KH * KW * Ci, x,
-           lambda: ops().conv2d_fwd(x, w, y, in_scale, out_scale, bias, residual, pad, pad_mode, act, per_sample_w,
-                                    stride, stats, deq))
+    return ops().conv2d_fwd(x, w, y, in_scale, out_scale, bias, residual, pad, pad_mode, act, per_sample_w, stride,
+                            stats, deq)
 
 
 AMAX_PARTIALS = 1024
@@ -271,12 +235,7 @@ def conv2d_wgrad(x, gy, dw, *, in_scale=None, gy_scale=None, pad, pad_mode, spli
     o2m_wgrad_desc.slabs) unless O2M_WGRAD_ATOMICS=1."""
     mx, mg = [p[0] for p in more], [p[1] for p in more]
     slabs = _slab_workspace(x, gy, dw, pad, pad_mode, splits, len(more), stride)
-    if PROFILE is None:
-        return ops().conv2d_wgrad(x, gy, dw, in_scale, gy_scale, pad, pad_mode, splits, mx, mg, stride, slabs)
-    Co, KH, KW, Ci = dw.shape
-    m = (1 + len(more)) * gy.shape[0] * gy.shape[1] * gy.shape[2]
-    _timed(_wgrad_name(x.dtype, Co, m, KH * KW * Ci), 2.0 * m * Co * KH * KW * Ci, x,
-           lambda: ops().conv2d_wgrad(x, gy, dw, in_scale, gy_scale, pad, pad_mode, splits, mx, mg, stride, slabs))
+    return ops().conv2d_wgrad(x, gy, dw, in_scale, gy_scale, pad, pad_mode, splits, mx, mg, stride, slabs)
 
 
 def act_bwd_reduce(g, y, residual, out_mul, gu, sums, act):

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #include "../../include/o2m_hip.h"
 
@@ -101,6 +102,30 @@ __device__ __forceinline__ int xcd_tile_order(int bid, int n) {
   const int q = n >> 3, r = n & 7;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
+
+// Per-kernel launch timing (o2m_launch_timing in include/o2m_hip.h): when switched on, every MFMA conv
+// launch site brackets its kernel with a HIP-event pair on the launch stream and files it under the
+// kernel's own name.  Off: one load of a flag.  Definitions in pointwise.hip.
+namespace o2m_timing {
+extern bool g_on;
+int open(const char* name, double flops, hipStream_t s);
+void close(int slot, hipStream_t s);
+}  // namespace o2m_timing
+struct LaunchScope {
+  hipStream_t s;
+  int slot = -1;
+  template <typename... A>
+  LaunchScope(hipStream_t s_, double flops, const char* fmt, A... a) : s(s_) {
+    if (o2m_timing::g_on) {
+      char name[64];
+      snprintf(name, sizeof(name), fmt, a...);
+      slot = o2m_timing::open(name, flops, s);
+    }
+  }
+  ~LaunchScope() {
+    if (slot >= 0) o2m_timing::close(slot, s);
+  }
+};
 
 #define O2M_LAUNCH_CHECK()                        \
   do {                                            \

@@ -123,6 +123,23 @@ __device__ __forceinline__ void stats_block_reduce(const float (&st)[16], float*
   }
 }
 
+// Division of an output-row index by a block-uniform divisor (pixels per sample, pixels per row) without
+// the ~35-instruction integer-division expansion per row: float reciprocal + one correction step, exact
+// for 0 <= m < 2^22 (the quotient estimate is then off by at most one); larger problems divide normally.
+struct RowDiv {
+  int d;
+  float r;
+  bool fast;
+  __device__ RowDiv(int d_, int limit) : d(d_), r(1.0f / (float)d_), fast(limit < (1 << 22)) {}
+  __device__ __forceinline__ int div(int m) const {
+    if (!fast) return m / d;
+    int q = (int)((float)m * r);
+    const int rem = m - q * d;
+    q += (rem >= d) - (rem < 0);
+    return q;
+  }
+};
+
 // WIDE: Ci % 64 == 0, so one 64-element stage lies inside ONE filter tap (tap-outer walk).
 // !WIDE: small Ci (image stems, Ci = 8..32): every 16-B chunk decodes its own tap.
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool IN_SCALE, bool WIDE>
@@ -198,13 +215,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
     return ((dlane & 15) ^ (pr & 15)) & 7;
   };
   const bool loader = !DMA || dwave < LW;  // wave-uniform
+  const RowDiv by_howo(HoWo, M), by_wo(Wo, M);
   int pix[FA], ryx[FA];
 #pragma unroll
   for (int j = 0; j < FA; ++j) {
     const int m = m0 + (DMA ? dma_row((dwave % LW) * FA + j) : r0 + RSTEP * j);
     if (m < M) {
-      const int b = m / HoWo, rem = m - b * HoWo;
-      const int oy = (rem / Wo) * S, ox = (rem - (rem / Wo) * Wo) * S;
+      const int b = by_howo.div(m), rem = m - b * HoWo;
+      const int q = by_wo.div(rem);
+      const int oy = q * S, ox = (rem - q * Wo) * S;
       pix[j] = (b * H + oy) * W + ox;
       ryx[j] = (oy << 16) | ox;
     } else {
@@ -229,11 +248,31 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
   // the zero padding / the row is outside M
   unsigned aoff[FA];  // byte offsets
   int cur_tap = -1;   // uniform
+  // Interior fills (DMA): every row of the fill has its whole KH x KW window inside the image.  Their
+  // lane offset points at the window's first tap and never changes; the tap moves only the fill's
+  // SGPR offset (tap_soff), so the walk costs such a fill no vector instructions at all.  Border fills
+  // (and rows past M) keep the per-tap offset with its padding test.
+  unsigned inner = 0;  // bit j: fill j is interior (wave-uniform)
+  unsigned tap_soff = 0;
+  if constexpr (DMA) {
+#pragma unroll
+    for (int j = 0; j < FA; ++j) {
+      const int oy = ryx[j] >> 16, ox = ryx[j] & 0xffff;
+      const bool in = pix[j] >= 0 && oy >= pad && oy - pad + KH <= H && ox >= pad && ox - pad + KW <= W;
+      if (__all(in)) {
+        inner |= 1u << j;
+        aoff[j] = (unsigned)((pix[j] - pad * W - pad) * Ci + dma_chk((dwave % LW) * FA + j) * 8) * ES;
+      }
+    }
+    inner = __builtin_amdgcn_readfirstlane(inner);  // tell the compiler: an SGPR (no waterfall around the fills)
+  }
 
   auto set_tap = [&](int tap) {
     const int dy = tap / KW - pad, dx = tap - (tap / KW) * KW - pad;  // scalar
+    if constexpr (DMA) tap_soff = (unsigned)(((dy + pad) * W + dx + pad) * Ci) * ES;
 #pragma unroll
     for (int j = 0; j < FA; ++j) {
+      if (DMA && (inner >> j & 1)) continue;
       const int oy = ryx[j] >> 16, ox = ryx[j] & 0xffff;
       int iy = oy + dy, ix = ox + dx;
       bool ok = pix[j] >= 0;
@@ -259,7 +298,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
   typedef __attribute__((address_space(3))) void lds_void;
 
   auto dma_tiles = [&](int kt, int stage) {
-    if (!loader) return;
+    if constexpr (LW < NW) {
+      if (!loader) return;
+    }
     const int k0 = kt * BK;
     const int tap = k0 / Ci;
     const int cbase = k0 - tap * Ci;
@@ -272,7 +313,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
     // (checked on hardware: tools/probe_buffer_lds.py), so the zero page is not needed here.
 #pragma unroll
     for (int j = 0; j < FA; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void*)(a_dst + j * 1024), 16, (int)aoff[j], cbase * 2, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          xr, (lds_void*)(a_dst + j * 1024), 16, (int)aoff[j],
+          __builtin_amdgcn_readfirstlane(cbase * 2 + ((inner >> j & 1) ? tap_soff : 0u)), 0, 0);
 #pragma unroll
     for (int j = 0; j < FB; ++j)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void*)(b_dst + j * 1024), 16, (int)dwoff[j], k0 * 2, 0, 0);
@@ -409,6 +452,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
 
   // ---- main loop: issue-early / write-late register staging --------------------------
   if constexpr (DMA) {
+    // Two stages, two blocks per CU: the partner block's MFMAs cover this block's fill latency, prologue
+    // and epilogue.  (Measured: a 3-stage ring with counted vmcnt needs > 80 KB, i.e. ONE block per CU, and
+    // lost 30-40 % on every short-reduction layer -- 128->64 3x3 at 256x256: 437 vs 615 TF/s.)
     dma_tiles(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -625,13 +671,14 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
   auto slot_row = [&](int q) { const int pr = 4 * q + (lane >> 4); return 2 * pr + (((lane & 15) ^ (pr & 15)) >> 3); };
   auto slot_chk = [&](int q) { const int pr = 4 * q + (lane >> 4); return ((lane & 15) ^ (pr & 15)) & 7; };
 
+  const RowDiv by_howo(HoWo, M), by_wo(Wo, M);
   int pix[4], ryx[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int m = m0 + slot_row(a_group(j));
     if (m < M) {
-      const int b = m / HoWo, rem = m - b * HoWo;
-      const int oy = rem / Wo, ox = rem - oy * Wo;
+      const int b = by_howo.div(m), rem = m - b * HoWo;
+      const int oy = by_wo.div(rem), ox = rem - oy * Wo;
       pix[j] = (b * H + oy) * W + ox;
       ryx[j] = (oy << 16) | ox;
     } else {
@@ -647,17 +694,35 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
     dwoff[j] = n < Co ? (unsigned)(n * K * ES + slot_chk(q) * 16) : OOB_OFF;
   }
   unsigned aoff[4];
+  // Interior fills: all 8 pixels of the fill have their whole KH x KW window inside the image.  Their lane
+  // offset points at the window's first tap once and for all; the tap only moves the fill's SGPR offset,
+  // so walking the taps costs such a fill no vector instructions.  Border fills keep the per-tap offsets.
+  unsigned inner = 0;  // bit j (wave-uniform)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int oy = ryx[j] >> 16, ox = ryx[j] & 0xffff;
+    const bool in = pix[j] >= 0 && oy >= pad && oy - pad + KH <= H && ox >= pad && ox - pad + KW <= W;
+    if (__all(in)) {
+      inner |= 1u << j;
+      aoff[j] = (unsigned)((pix[j] - pad * W - pad) * Ci * ES + slot_chk(a_group(j)) * 16);
+    }
+  }
+  inner = __builtin_amdgcn_readfirstlane(inner);
   // per-region stream state (wave-uniform): next K-tile's tap (ky, kx), channel base, LDS buffer
   int a_ky[2] = {0, 0}, a_kx[2] = {0, 0}, a_cb[2] = {0, 0}, a_buf[2] = {0, 0};
+  unsigned a_tap[2] = {0, 0};  // byte offset of the tap inside the window (interior fills)
   int b_kt[2] = {0, 0};
 
   auto issue_a = [&](int r) {
     if (a_cb[r] == 0) {  // first K-tile of a tap: gather offsets of this region's two fills
       const int dy = a_ky[r] - pad, dx = a_kx[r] - pad;
       const bool live = a_ky[r] < KH;  // past the reduction: zero fills, no traffic
+      if (!live) inner &= ~(3u << (2 * r));
+      a_tap[r] = (unsigned)((a_ky[r] * W + a_kx[r]) * Ci * ES);
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
         const int j = 2 * r + jj;
+        if (inner >> j & 1) continue;
         const int oy = ryx[j] >> 16, ox = ryx[j] & 0xffff;
         int iy = oy + dy, ix = ox + dx;
         bool ok = live && pix[j] >= 0;
@@ -674,7 +739,9 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
       const int j = 2 * r + jj;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void*)(dst + a_group(j) * 1024), 16, (int)aoff[j], a_cb[r] * ES, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          xr, (lds_void*)(dst + a_group(j) * 1024), 16, (int)aoff[j],
+          __builtin_amdgcn_readfirstlane(a_cb[r] * ES + ((inner >> j & 1) ? a_tap[r] : 0u)), 0, 0);
     }
     a_buf[r] ^= 1;
     a_cb[r] += KT;
@@ -900,15 +967,19 @@ int launch_p8(const o2m_conv_desc& d, hipStream_t s, long m_begin, long m_end) {
   auto kern = d.dtype == O2M_FP8_E4M3 ? conv_igemm_p8_kernel<1>
                                       : (d.dtype == O2M_BF8_E5M2 ? conv_igemm_p8_kernel<2> : conv_igemm_p8_kernel<0>);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), lds, s, d, (int)m_begin, (int)m_end);
+  {
+    LaunchScope timed(s, 2.0 * (m_end - m_begin) * d.Co * d.KH * d.KW * d.Ci, "conv_igemm_p8<%s,256x256>",
+                      d.dtype == O2M_BF16 ? "bf16" : "fp8");
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), lds, s, d, (int)m_begin, (int)m_end);
+  }
   O2M_LAUNCH_CHECK();
   return 0;
 }
 
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
 int launch_cfg(const o2m_conv_desc& d, hipStream_t s, long m_begin = 0, long m_end = -1) {
-  constexpr int lds = lds_bytes<T, BM, BN, WAVES_M, WAVES_N>();
   constexpr int NT = 64 * WAVES_M * WAVES_N;
+  constexpr int lds = lds_bytes<T, BM, BN, WAVES_M, WAVES_N>();
   if (m_end < 0) m_end = out_rows(d);
   const long tiles = tiles_rows<BM, BN>(d, m_end - m_begin);
   if (tiles <= 0 || tiles > 0x7fffffffL) return O2M_ERR_BAD_ARG;
@@ -918,6 +989,8 @@ int launch_cfg(const o2m_conv_desc& d, hipStream_t s, long m_begin = 0, long m_e
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(NT), lds, s, d, (int)m_begin, (int)m_end);
   };
   const bool wide = d.Ci % BK == 0;
+  LaunchScope timed(s, 2.0 * (m_end - m_begin) * d.Co * d.KH * d.KW * d.Ci, "conv_igemm<%s,%dx%d,in_scale=%d>",
+                    sizeof(T) == 2 ? "bf16" : "f32x3", BM, BN, d.in_scale ? 1 : 0);
   if (d.in_scale) {
     if (wide) go(conv_igemm_kernel<T, BM, BN, WAVES_M, WAVES_N, true, true>);
     else go(conv_igemm_kernel<T, BM, BN, WAVES_M, WAVES_N, true, false>);

@@ -415,11 +415,15 @@ int launch_cfg(const o2m_wgrad_desc& d, hipStream_t s, size_t* slab_floats = nul
     else if (gs) go(conv_wgrad_kernel<T, BCO, BKO, WAVES_CO, WAVES_K, false, true, AL>);
     else go(conv_wgrad_kernel<T, BCO, BKO, WAVES_CO, WAVES_K, false, false, AL>);
   };
-  if (Wo % BMR == 0) pick(std::true_type{});
-  else pick(std::false_type{});
+  {
+    LaunchScope timed(s, 2.0 * M * d.Co * K, "conv_wgrad<%s,co%dxk%d>", sizeof(T) == 2 ? "bf16" : "f32x3", BCO, BKO);
+    if (Wo % BMR == 0) pick(std::true_type{});
+    else pick(std::false_type{});
+  }
   O2M_LAUNCH_CHECK();
   if (d.slabs) {
     const long n4 = (long)d.Co * K / 4;  // Ci % 8 == 0, so K % 8 == 0
+    LaunchScope timed(s, 0.0, "%s", "wgrad_reduce");
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, d.dw, d.slabs,
                        (int)splits, n4);
     O2M_LAUNCH_CHECK();

@@ -705,9 +705,76 @@ inline unsigned grid_for(long n, int per_block = NT) {
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------- launch timing
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace o2m_timing {
+bool g_on = false;
+namespace {
+struct Rec {
+  std::string name;
+  double flops;
+  hipEvent_t e0, e1;
+};
+std::mutex g_mu;  // forward runs on the caller's thread, backward on autograd's device thread
+std::vector<Rec> g_recs;
+}  // namespace
+
+int open(const char* name, double flops, hipStream_t s) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  Rec r{name, flops, nullptr, nullptr};
+  if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return -1;
+  (void)hipEventRecord(r.e0, s);
+  g_recs.push_back(r);
+  return (int)g_recs.size() - 1;
+}
+
+void close(int slot, hipStream_t s) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  if (slot >= 0 && slot < (int)g_recs.size()) (void)hipEventRecord(g_recs[slot].e1, s);
+}
+}  // namespace o2m_timing
+
 extern "C" {
 
-int o2m_abi_version(void) { return 15; }
+int o2m_abi_version(void) { return 16; }
+
+int32_t o2m_launch_timing(int32_t enable) {
+  std::lock_guard<std::mutex> lock(o2m_timing::g_mu);
+  const int32_t was = o2m_timing::g_on;
+  o2m_timing::g_on = enable != 0;
+  return was;
+}
+
+int32_t o2m_launch_timing_read(o2m_launch_stat* out, int32_t capacity) {
+  using namespace o2m_timing;
+  if (capacity < 0 || (capacity > 0 && !out)) return -O2M_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> lock(g_mu);
+  int32_t n = 0, err = 0;
+  for (Rec& r : g_recs) {
+    float ms = 0.f;
+    if (hipEventSynchronize(r.e1) != hipSuccess || hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) err = 1;
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
+    int32_t i = 0;
+    while (i < n && r.name != out[i].kernel) ++i;
+    if (i == n) {
+      if (n == capacity) continue;  // table full: the remaining kernels are dropped, the count says so
+      snprintf(out[i].kernel, sizeof(out[i].kernel), "%s", r.name.c_str());
+      out[i].launches = 0;
+      out[i].ms = 0.f;
+      out[i].flops = 0.0;
+      ++n;
+    }
+    out[i].launches += 1;
+    out[i].ms += ms;
+    out[i].flops += r.flops;
+  }
+  g_recs.clear();
+  return err ? -1 : n;
+}
 
 int o2m_amax(const void* x, float* amax, int64_t n, int32_t dtype, void* stream) {
   if (!x || !amax || n <= 0 || (n & 7)) return O2M_ERR_BAD_ARG;
