@@ -225,7 +225,11 @@ int o2m_wgrad_finalize(float* acc, float* gq, const float* w32, float* grad, int
  * modulated conv and the bias need:
  *   sums[b,0,c] = sum_p gu ,  sums[b,1,c] = sum_p gu * (y - residual)
  * (second sum gives d loss / d out_scale = sums1 / out_scale for act in {none, relu}).
- * sums is fp32 [B][2][C], zeroed by the caller (accumulated with atomics).  If out_mul
+ * sums is fp32 [B][2][C], zeroed by the caller and ADDED to: with fp32 atomics from every pixel
+ * chunk (partials NULL), or -- the reference's deterministic_cuda_kernels mode, train.py:41-45 --
+ * through `partials`, caller workspace of o2m_chan_partials_floats(B, P, C, 2) floats: every chunk
+ * stores its row there and a second launch adds the rows in chunk order (bitwise reproducible).
+ * If out_mul
  * ([B][C] fp32) is given the STORED tensor is gu * out_mul[b,c] (the demodulation factor is
  * folded here so that dgrad and wgrad of the modulated conv read it pre-scaled); the sums
  * always use the unscaled gu.
@@ -234,9 +238,10 @@ int o2m_wgrad_finalize(float* acc, float* gq, const float* w32, float* grad, int
  * Reduce-only form (the bias gradient of a conv with no activation, layers.py:84-100): y = NULL
  * with act = O2M_ACT_NONE and no residual; gu may then be NULL as well (nothing is stored).
  */
+size_t o2m_chan_partials_floats(int32_t B, int32_t P, int32_t C, int32_t nv);
 int o2m_act_bwd_reduce(const void* g, const void* y, const void* residual,
                        const float* out_mul, void* gu, float* sums, int32_t B, int32_t P,
-                       int32_t C, int32_t act, int32_t dtype, void* stream);
+                       int32_t C, int32_t act, int32_t dtype, float* partials, void* stream);
 
 /* Backward of ReflectionPad2d fused with the style scale and the style-gradient dot:
  *   gfold = fold_reflect(gpad)             (pad == 0: identity)
@@ -245,10 +250,12 @@ int o2m_act_bwd_reduce(const void* g, const void* y, const void* residual,
  *   xs[b,y,x,c]   = x[b,y,x,c] * scale[b,c]                  (xs NULL: skipped; needs dots)
  * gpad is [B][H+2p][W+2p][C]; gx, x, xs are [B][H][W][C]; dots fp32 [B][C] zeroed by caller.
  * xs is the modulated input, a by-product for o2m_conv2d_wgrad (x is being read anyway).
+ * partials: NULL (fp32 atomics into dots) or o2m_chan_partials_floats(B, H*W, C, 1) floats of
+ * workspace for the ordered two-stage sum, as in o2m_act_bwd_reduce.
  */
 int o2m_fold_scale_dot(const void* gpad, const void* x, const float* scale, void* gx,
                        float* dots, void* xs, int32_t B, int32_t H, int32_t W, int32_t C,
-                       int32_t pad, int32_t dtype, void* stream);
+                       int32_t pad, int32_t dtype, float* partials, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * InstanceNorm2d (eps, biased variance, no affine; builder.py:164,172,273..; blocks.py:23,27)

@@ -32,7 +32,7 @@ BF16, F32, FP8_E4M3, BF8_E5M2 = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 PAD_ZERO, PAD_REFLECT = 0, 1
 RED_L1, RED_SQ, RED_MOM = 0, 1, 2
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -69,11 +69,12 @@ SIGNATURES = {
     "o2m_wgrad_finalize": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
     "o2m_style_fwd": (_i32, [_vp] * 6 + [_i32] * 5 + [_f32, _f32, _vp]),
     "o2m_style_bwd": (_i32, [_vp] * 14 + [_i32] * 5 + [_f32, _i32, _vp]),
-    "o2m_act_bwd_reduce": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "o2m_chan_partials_floats": (C.c_size_t, [_i32, _i32, _i32, _i32]),
+    "o2m_act_bwd_reduce": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "o2m_prepare_weights": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, C.c_float,
                                    _i32, _vp]),
     "o2m_modulate_weights": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
-    "o2m_fold_scale_dot": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "o2m_fold_scale_dot": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "o2m_instnorm_ws_floats": (C.c_size_t, [_i32, _i32, _i32]),
     "o2m_instnorm_stats": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp]),
     "o2m_instnorm_apply": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
@@ -94,6 +95,7 @@ SIGNATURES = {
 }
 
 _lib = None
+MEASUREMENT_ONLY = {"o2m_launch_timing", "o2m_launch_timing_read"}  # C-ABI entries without a torch.ops.o2m twin
 
 
 class LaunchStat(C.Structure):
@@ -220,7 +222,7 @@ WGRAD_ATOMICS = os.environ.get("O2M_WGRAD_ATOMICS", "0") == "1"  # A/B: float at
 
 
 def _slab_workspace(x, gy, dw, pad, pad_mode, splits, n_more, stride):
-    if WGRAD_ATOMICS:
+    if WGRAD_ATOMICS and not DETERMINISTIC:
         return None
     need = ops().conv2d_wgrad_slab_floats(x, gy, dw, pad, pad_mode, splits, n_more, stride)
     ws = _SLABS.get(x.device)
@@ -238,8 +240,24 @@ def conv2d_wgrad(x, gy, dw, *, in_scale=None, gy_scale=None, pad, pad_mode, spli
     return ops().conv2d_wgrad(x, gy, dw, in_scale, gy_scale, pad, pad_mode, splits, mx, mg, stride, slabs)
 
 
+DETERMINISTIC = False  # ops.set_deterministic(): ordered two-stage sums instead of fp32 atomics
+_PARTIALS: dict = {}   # device -> fp32 workspace of the per-chunk rows
+
+
+def _chan_partials(g, P, nv):
+    """Workspace for the ordered channel sums (None outside deterministic mode: fp32 atomics)."""
+    if not DETERMINISTIC:
+        return None
+    need = ops().chan_partials_floats(g.shape[0], P, g.shape[-1], nv)
+    ws = _PARTIALS.get(g.device)
+    if ws is None or ws.numel() < need:
+        ws = _PARTIALS[g.device] = torch.empty(max(need, 1 << 20), dtype=torch.float32, device=g.device)
+    return ws
+
+
 def act_bwd_reduce(g, y, residual, out_mul, gu, sums, act):
-    ops().act_bwd_reduce(g, y, residual, out_mul, gu, sums, act)
+    partials = _chan_partials(g, g.shape[1] * g.shape[2], 2) if sums is not None else None
+    ops().act_bwd_reduce(g, y, residual, out_mul, gu, sums, act, partials)
 
 
 def style_fwd(w, ws, bs, qt, s, d, ci, cs, eps):
@@ -265,7 +283,8 @@ def modulate_weights(w32, s, out):
 
 
 def fold_scale_dot(gpad, x, scale, gx, dots, pad, xs=None):
-    ops().fold_scale_dot(gpad, x, scale, gx, dots, pad, xs)
+    partials = _chan_partials(gx, gx.shape[1] * gx.shape[2], 1) if dots is not None else None
+    ops().fold_scale_dot(gpad, x, scale, gx, dots, pad, xs, partials)
 
 
 def instnorm_ws_floats(B, P, Cn):

@@ -51,7 +51,8 @@ __global__ __launch_bounds__(NT) void act_bwd_reduce_kernel(const T* __restrict_
                                                             const T* __restrict__ res,
                                                             const float* __restrict__ out_mul,
                                                             T* __restrict__ gu, float* __restrict__ sums,
-                                                            int P, int C, int act, ChanGeom gm) {
+                                                            float* __restrict__ partials, int P, int C, int act,
+                                                            ChanGeom gm) {
   extern __shared__ float sm[];
   const int b = blockIdx.y, ch = blockIdx.x;
   const int cv = threadIdx.x % gm.CV, pl = threadIdx.x / gm.CV;
@@ -89,7 +90,24 @@ __global__ __launch_bounds__(NT) void act_bwd_reduce_kernel(const T* __restrict_
     for (int i = 0; i < 8; ++i) { sm[cv * 8 + i] = acc[i]; sm[C + cv * 8 + i] = acc[8 + i]; }
   }
   __syncthreads();
-  for (int t = threadIdx.x; t < 2 * C; t += NT) atomicAdd(sums + (size_t)b * 2 * C + t, sm[t]);
+  // deterministic mode: this chunk's row goes to the workspace (one writer per element) and
+  // chunk_sum_kernel adds the rows in chunk order; else fp32 atomics straight into sums
+  if (partials) {
+    for (int t = threadIdx.x; t < 2 * C; t += NT) partials[((size_t)b * gridDim.x + ch) * 2 * C + t] = sm[t];
+  } else {
+    for (int t = threadIdx.x; t < 2 * C; t += NT) atomicAdd(sums + (size_t)b * 2 * C + t, sm[t]);
+  }
+}
+
+// out[b][t] += sum over the chunks, in chunk order (fixed summation order: bitwise reproducible)
+__global__ __launch_bounds__(NT) void chunk_sum_kernel(float* __restrict__ out, const float* __restrict__ partials,
+                                                       int nchunks, int n) {
+  const int b = blockIdx.x;
+  for (int t = threadIdx.x; t < n; t += NT) {
+    float a = out[(size_t)b * n + t];
+    for (int c = 0; c < nchunks; ++c) a += partials[((size_t)b * nchunks + c) * n + t];
+    out[(size_t)b * n + t] = a;
+  }
 }
 
 // ---- reflect-pad backward (fold) + style scale + style dot ----------------------------------
@@ -97,8 +115,8 @@ template <typename T>
 __global__ __launch_bounds__(NT) void fold_scale_dot_kernel(const T* __restrict__ gpad, const T* __restrict__ x,
                                                             const float* __restrict__ scale,
                                                             T* __restrict__ gx, float* __restrict__ dots,
-                                                            T* __restrict__ xmod, int H, int W, int C,
-                                                            int pad, ChanGeom gm) {
+                                                            T* __restrict__ xmod, float* __restrict__ partials,
+                                                            int H, int W, int C, int pad, ChanGeom gm) {
   extern __shared__ float sm[];
   const int b = blockIdx.y, ch = blockIdx.x;
   const int cv = threadIdx.x % gm.CV, pl = threadIdx.x / gm.CV;
@@ -155,7 +173,11 @@ __global__ __launch_bounds__(NT) void fold_scale_dot_kernel(const T* __restrict_
 #pragma unroll
       for (int i = 0; i < 8; ++i) sm[cv * 8 + i] = acc[i];
     __syncthreads();
-    for (int t = threadIdx.x; t < C; t += NT) atomicAdd(dots + (size_t)b * C + t, sm[t]);
+    if (partials) {
+      for (int t = threadIdx.x; t < C; t += NT) partials[((size_t)b * gridDim.x + ch) * C + t] = sm[t];
+    } else {
+      for (int t = threadIdx.x; t < C; t += NT) atomicAdd(dots + (size_t)b * C + t, sm[t]);
+    }
   }
 }
 
@@ -739,7 +761,7 @@ void close(int slot, hipStream_t s) {
 
 extern "C" {
 
-int o2m_abi_version(void) { return 16; }
+int o2m_abi_version(void) { return 17; }
 
 int32_t o2m_launch_timing(int32_t enable) {
   std::lock_guard<std::mutex> lock(o2m_timing::g_mu);
@@ -825,9 +847,14 @@ int o2m_prepare_weights(const float* w, float* full, void* w_f, void* w_d, float
   return 0;
 }
 
+size_t o2m_chan_partials_floats(int32_t B, int32_t P, int32_t C, int32_t nv) {
+  if (B <= 0 || P <= 0 || C <= 0 || nv <= 0) return 0;
+  return (size_t)B * chan_geom(B, P, C).nchunks * nv * C;
+}
+
 int o2m_act_bwd_reduce(const void* g, const void* y, const void* residual, const float* out_mul,
                        void* gu, float* sums, int32_t B, int32_t P, int32_t C, int32_t act,
-                       int32_t dtype, void* stream) {
+                       int32_t dtype, float* partials, void* stream) {
   if (!g || !sums || B <= 0 || P <= 0 || C <= 0 || (C & 7) || C > 8 * NT) return O2M_ERR_BAD_ARG;
   // y may be omitted only for the identity activation without residual (reduce-only: gu optional)
   if (!y && (act != O2M_ACT_NONE || residual)) return O2M_ERR_BAD_ARG;
@@ -837,14 +864,18 @@ int o2m_act_bwd_reduce(const void* g, const void* y, const void* residual, const
   hipStream_t s = static_cast<hipStream_t>(stream);
   DISPATCH_T(dtype, hipLaunchKernelGGL(act_bwd_reduce_kernel<T>, dim3(gm.nchunks, B), dim3(NT), lds, s,
                                        (const T*)g, (const T*)y, (const T*)residual, out_mul, (T*)gu,
-                                       sums, P, C, act, gm));
+                                       sums, partials, P, C, act, gm));
   O2M_LAUNCH_CHECK();
+  if (partials) {
+    hipLaunchKernelGGL(chunk_sum_kernel, dim3(B), dim3(NT), 0, s, sums, partials, gm.nchunks, 2 * C);
+    O2M_LAUNCH_CHECK();
+  }
   return 0;
 }
 
 int o2m_fold_scale_dot(const void* gpad, const void* x, const float* scale, void* gx, float* dots,
                        void* xs, int32_t B, int32_t H, int32_t W, int32_t C, int32_t pad, int32_t dtype,
-                       void* stream) {
+                       float* partials, void* stream) {
   if (!gpad || !gx || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7) || C > 8 * NT || pad < 0)
     return O2M_ERR_BAD_ARG;
   if (pad >= H || pad >= W || (dots && !x) || (xs && !dots)) return O2M_ERR_BAD_ARG;
@@ -852,9 +883,13 @@ int o2m_fold_scale_dot(const void* gpad, const void* x, const float* scale, void
   const size_t lds = (size_t)gm.PL * gm.CV * 8 * sizeof(float);
   hipStream_t s = static_cast<hipStream_t>(stream);
   DISPATCH_T(dtype, hipLaunchKernelGGL(fold_scale_dot_kernel<T>, dim3(gm.nchunks, B), dim3(NT), lds, s,
-                                       (const T*)gpad, (const T*)x, scale, (T*)gx, dots, (T*)xs, H, W, C,
-                                       pad, gm));
+                                       (const T*)gpad, (const T*)x, scale, (T*)gx, dots, (T*)xs,
+                                       dots ? partials : nullptr, H, W, C, pad, gm));
   O2M_LAUNCH_CHECK();
+  if (dots && partials) {
+    hipLaunchKernelGGL(chunk_sum_kernel, dim3(B), dim3(NT), 0, s, dots, partials, gm.nchunks, C);
+    O2M_LAUNCH_CHECK();
+  }
   return 0;
 }
 

@@ -56,14 +56,14 @@ __global__ __launch_bounds__(NT) void style_fwd_kernel(const float* w, const flo
 }
 
 // grid (B, ceil(Cip/64)): e (recomputed per block into LDS), then 64 input channels x 4 slices
-// of the reduction over o; gw is accumulated with atomics (zeroed by the caller).
+// of the reduction over o.  (gw, the gradient of the latent, is formed by style_bwd_batch_kernel from the
+// finished gs rows: one block per sample, fixed summation order, no atomics.)
 __global__ __launch_bounds__(NT) void style_bwd_sample_kernel(
     const float* sums, const float* bias, const float* dots, const float* s, const float* d, const float* Q,
-    const float* Ws, float* e, float* gs, float* gw, int WD, int Ci, int Cip, int Cop, float cs) {
-  extern __shared__ float sm[];  // es[Cop], part[4][64], gsl[64]
+    float* e, float* gs, int Ci, int Cip, int Cop) {
+  extern __shared__ float sm[];  // es[Cop], part[4][64]
   float* es = sm;
   float* part = sm + Cop;
-  float* gsl = part + 256;
   const int b = blockIdx.x;
   if (d) {
     for (int o = threadIdx.x; o < Cop; o += NT) {
@@ -92,24 +92,36 @@ __global__ __launch_bounds__(NT) void style_bwd_sample_kernel(
       if (d) g += 2.f * s[(size_t)b * Cip + i] * (part[il] + part[64 + il] + part[128 + il] + part[192 + il]);
     }
     if (i < Cip) gs[(size_t)b * Cip + i] = g;
-    gsl[il] = g;
-  }
-  __syncthreads();
-  if ((int)threadIdx.x < WD) {  // gw[b][j] += cs * sum_i gs[i] Ws[i][j] over this block's 64 channels
-    float a = 0.f;
-    for (int q = 0; q < 64; ++q) {
-      const int ii = blockIdx.y * 64 + q;
-      if (ii < Ci) a += gsl[q] * Ws[(size_t)ii * WD + threadIdx.x];
-    }
-    atomicAdd(gw + (size_t)b * WD + threadIdx.x, a * cs);
   }
 }
 
-// over the batch: gWs, gbs (block 0 .. ) and gq rows
+// blocks [0, param_blocks): gWs, gbs (over the batch); then B blocks: gw[b][:] = cs * gs[b][:] Ws; then the gq rows
 __global__ __launch_bounds__(NT) void style_bwd_batch_kernel(const float* gs, const float* w, const float* e,
-                                                             const float* s, float* gWs, float* gbs, float* gq,
-                                                             int B, int WD, int Ci, int Cip, int Cop, float cs,
-                                                             int param_blocks, int accumulate) {
+                                                             const float* s, const float* Ws, float* gWs, float* gbs,
+                                                             float* gw, float* gq, int B, int WD, int Ci, int Cip,
+                                                             int Cop, float cs, int param_blocks, int accumulate) {
+  if ((int)blockIdx.x >= param_blocks && (int)blockIdx.x < param_blocks + B) {
+    __shared__ float red[NT][MAXWD];
+    const int b = blockIdx.x - param_blocks;
+    float a[MAXWD];
+#pragma unroll
+    for (int j = 0; j < MAXWD; ++j) a[j] = 0.f;
+    for (int i = threadIdx.x; i < Ci; i += NT) {
+      const float g = gs[(size_t)b * Cip + i];
+#pragma unroll
+      for (int j = 0; j < MAXWD; ++j)
+        if (j < WD) a[j] += g * Ws[(size_t)i * WD + j];
+    }
+#pragma unroll
+    for (int j = 0; j < MAXWD; ++j) red[threadIdx.x][j] = a[j];
+    __syncthreads();
+    if ((int)threadIdx.x < WD) {
+      float t = 0.f;
+      for (int q = 0; q < NT; ++q) t += red[q][threadIdx.x];
+      gw[(size_t)b * WD + threadIdx.x] = t * cs;
+    }
+    return;
+  }
   if ((int)blockIdx.x < param_blocks) {
     const int i = blockIdx.x * NT + threadIdx.x;
     if (i >= Ci) return;
@@ -132,7 +144,7 @@ __global__ __launch_bounds__(NT) void style_bwd_batch_kernel(const float* gs, co
     return;
   }
   if (!gq) return;
-  const int o = blockIdx.x - param_blocks;  // one block per output channel row of gq
+  const int o = blockIdx.x - param_blocks - B;  // one block per output channel row of gq
   for (int i = threadIdx.x; i < Cip; i += NT) {
     float a = 0.f;
 #pragma unroll 8
@@ -167,14 +179,13 @@ int o2m_style_bwd(const float* sums, const float* bias, const float* dots, const
   if (B <= 0 || WD <= 0 || WD > MAXWD || Ci <= 0 || Cip < Ci || Cop <= 0) return O2M_ERR_BAD_ARG;
   if (d && (!sums || !Q || !e || !gq)) return O2M_ERR_BAD_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const size_t lds = (Cop + 256 + 64) * sizeof(float);
-  (void)hipMemsetAsync(gw, 0, (size_t)B * WD * sizeof(float), st);
+  const size_t lds = (Cop + 256) * sizeof(float);
   hipLaunchKernelGGL(style_bwd_sample_kernel, dim3(B, (Cip + 63) / 64), dim3(NT), lds, st, sums, bias, dots, s, d,
-                     Q, Ws, e, gs, gw, WD, Ci, Cip, Cop, cs);
+                     Q, e, gs, Ci, Cip, Cop);
   O2M_LAUNCH_CHECK();
   const int pb = (Ci + NT - 1) / NT;
-  hipLaunchKernelGGL(style_bwd_batch_kernel, dim3(pb + (d ? Cop : 0)), dim3(NT), 0, st, gs, w, e, s, gWs, gbs,
-                     d ? gq : nullptr, B, WD, Ci, Cip, Cop, cs, pb, accumulate);
+  hipLaunchKernelGGL(style_bwd_batch_kernel, dim3(pb + B + (d ? Cop : 0)), dim3(NT), 0, st, gs, w, e, s, Ws, gWs, gbs,
+                     gw, d ? gq : nullptr, B, WD, Ci, Cip, Cop, cs, pb, accumulate);
   O2M_LAUNCH_CHECK();
   return 0;
 }

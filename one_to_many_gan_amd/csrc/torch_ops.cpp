@@ -286,7 +286,7 @@ void style_bwd(const OptT& sums, const OptT& bias, const OptT& dots, const Tenso
 // -------------------------------------------------------------------------------- pointwise
 
 void act_bwd_reduce(const Tensor& g, const OptT& y, const OptT& residual, const OptT& out_mul, const std::optional<Tensor>& gu,
-                    const std::optional<Tensor>& sums, int64_t act) {
+                    const std::optional<Tensor>& sums, int64_t act, const std::optional<Tensor>& partials) {
   const char* op = "o2m::act_bwd_reduce";
   chk(g, op, "g"); chk(y, op, "y"); chk(residual, op, "residual"); chk_f32(out_mul, op, "out_mul"); chk(gu, op, "gu"); chk_f32(sums, op, "sums");
   TORCH_CHECK(g.dim() == 4, op, ": g is NHWC");
@@ -294,13 +294,17 @@ void act_bwd_reduce(const Tensor& g, const OptT& y, const OptT& residual, const 
   TORCH_CHECK(!y.has_value() || y->sizes() == g.sizes(), op, ": y must have g's shape");
   TORCH_CHECK(!gu.has_value() || gu->sizes() == g.sizes(), op, ": gu must have g's shape");
   TORCH_CHECK(!sums.has_value() || sums->numel() == g.size(0) * 2 * g.size(3), op, ": sums is [B][2][C]");
+  chk_f32(partials, op, "partials");
+  TORCH_CHECK(!partials.has_value() ||
+                  partials->numel() >= static_cast<int64_t>(o2m_chan_partials_floats(g.size(0), g.size(1) * g.size(2), g.size(3), 2)),
+              op, ": partials workspace too small");
   const int dt_g = dtype_code(g, op);
   O2M_CALL(op, g, o2m_act_bwd_reduce(ptr(g), ptr(y), ptr(residual), fptr(out_mul), ptr(gu), ptr<float>(sums), i32(g.size(0), op),
-                                    i32(g.size(1) * g.size(2), op), i32(g.size(3), op), i32(act, op), dt_g, stream));
+                                    i32(g.size(1) * g.size(2), op), i32(g.size(3), op), i32(act, op), dt_g, ptr<float>(partials), stream));
 }
 
 void fold_scale_dot(const Tensor& gpad, const OptT& x, const OptT& scale, Tensor& gx, const std::optional<Tensor>& dots, int64_t pad,
-                    const std::optional<Tensor>& xs) {
+                    const std::optional<Tensor>& xs, const std::optional<Tensor>& partials) {
   const char* op = "o2m::fold_scale_dot";
   chk(gpad, op, "gpad"); chk(x, op, "x"); chk_f32(scale, op, "scale"); chk(gx, op, "gx"); chk_f32(dots, op, "dots"); chk(xs, op, "xs");
   TORCH_CHECK(gx.dim() == 4 && gpad.dim() == 4, op, ": gpad, gx are NHWC");
@@ -309,9 +313,19 @@ void fold_scale_dot(const Tensor& gpad, const OptT& x, const OptT& scale, Tensor
                   gpad.size(3) == gx.size(3), op, ": gpad must be gx's shape plus the padding margins");
   TORCH_CHECK(!x.has_value() || x->sizes() == gx.sizes(), op, ": x must have gx's shape");
   TORCH_CHECK(!xs.has_value() || xs->sizes() == gx.sizes(), op, ": xs must have gx's shape");
+  chk_f32(partials, op, "partials");
+  TORCH_CHECK(!partials.has_value() ||
+                  partials->numel() >= static_cast<int64_t>(o2m_chan_partials_floats(gx.size(0), gx.size(1) * gx.size(2), gx.size(3), 1)),
+              op, ": partials workspace too small");
   const int dt_gx = dtype_code(gx, op);
   O2M_CALL(op, gx, o2m_fold_scale_dot(ptr(gpad), ptr(x), fptr(scale), ptr(gx), ptr<float>(dots), ptr(xs), i32(gx.size(0), op),
-                                     i32(gx.size(1), op), i32(gx.size(2), op), i32(gx.size(3), op), i32(pad, op), dt_gx, stream));
+                                     i32(gx.size(1), op), i32(gx.size(2), op), i32(gx.size(3), op), i32(pad, op), dt_gx,
+                                     ptr<float>(partials), stream));
+}
+
+int64_t chan_partials_floats(int64_t B, int64_t P, int64_t C, int64_t nv) {
+  const char* op = "o2m::chan_partials_floats";
+  return static_cast<int64_t>(o2m_chan_partials_floats(i32(B, op), i32(P, op), i32(C, op), i32(nv, op)));
 }
 
 int64_t instnorm_ws_floats(int64_t B, int64_t P, int64_t C) {
@@ -516,8 +530,9 @@ TORCH_LIBRARY(o2m, m) {
   m.def("style_fwd(Tensor w, Tensor ws, Tensor bs, Tensor? qt, Tensor(a!) s, Tensor(b!)? d, int ci, float cs, float eps) -> ()");
   m.def("style_bwd(Tensor? sums, Tensor? bias, Tensor? dots, Tensor s, Tensor? d, Tensor? q, Tensor w, Tensor ws, Tensor(a!)? e, "
         "Tensor(b!) gs, Tensor(c!) gw, Tensor(d!) gws, Tensor(e!) gbs, Tensor(f!)? gq, int ci, float cs, bool accumulate) -> ()");
-  m.def("act_bwd_reduce(Tensor g, Tensor? y, Tensor? residual, Tensor? out_mul, Tensor(a!)? gu, Tensor(b!)? sums, int act) -> ()");
-  m.def("fold_scale_dot(Tensor gpad, Tensor? x, Tensor? scale, Tensor(a!) gx, Tensor(b!)? dots, int pad, Tensor(c!)? xs) -> ()");
+  m.def("act_bwd_reduce(Tensor g, Tensor? y, Tensor? residual, Tensor? out_mul, Tensor(a!)? gu, Tensor(b!)? sums, int act, Tensor(c!)? partials=None) -> ()");
+  m.def("fold_scale_dot(Tensor gpad, Tensor? x, Tensor? scale, Tensor(a!) gx, Tensor(b!)? dots, int pad, Tensor(c!)? xs, Tensor(d!)? partials=None) -> ()");
+  m.def("chan_partials_floats(int B, int P, int C, int nv) -> int", &chan_partials_floats);
   m.def("instnorm_stats(Tensor x, Tensor(a!) partial, Tensor(b!) mean_rstd, float eps) -> ()");
   m.def("instnorm_apply(Tensor x, Tensor mean_rstd, Tensor? residual, Tensor(a!) y, int act) -> ()");
   m.def("instnorm_bwd(Tensor g, Tensor x, Tensor mean_rstd, Tensor(a!) partial, Tensor(b!) gsums, Tensor(c!) gx, int act) -> ()");

@@ -52,8 +52,12 @@ def _quantize(t: torch.Tensor, fmt: torch.dtype, deq_pair: torch.Tensor) -> torc
 def set_deterministic(flag: bool) -> None:
     """The reference's ``deterministic_cuda_kernels`` switch (train.py:41-45, config.toml:9): when on,
     every kernel that sums across workgroups with float atomics takes its two-stage, fixed-order
-    form instead, so two runs of a step are bitwise equal."""
+    form instead, so two runs of a step are bitwise equal: the per-(sample, channel) sums of
+    act_bwd_reduce and fold_scale_dot go through per-chunk rows added in chunk order (o2m_hip.h), and the
+    weight gradient keeps its slab + ordered sum even under O2M_WGRAD_ATOMICS=1.  (The weight gradient's
+    default form, InstanceNorm, the loss reductions and the style gradients are order-fixed in both modes.)"""
     _STATE["deterministic"] = bool(flag)
+    H.DETERMINISTIC = bool(flag)
 
 
 def deterministic() -> bool:

@@ -178,3 +178,21 @@ def test_training_steps_match_reference(name, precision, golden_dir):
         if err > tol:
             bad.append((k, err, tol))
     assert not bad, bad
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_deterministic_mode_makes_training_steps_bitwise_reproducible(precision):
+    """The reference's ``deterministic_cuda_kernels`` switch (train.py:41-45): with
+    ``set_deterministic(True)`` two runs of the same two D+G steps (Adam included) agree bit for bit --
+    losses and the post-step probes of all four networks."""
+    import one_to_many_gan_amd as pk
+
+    pk.set_deterministic(True)
+    try:
+        a = run_case("steps64", product_ns(precision), "cuda")
+        b = run_case("steps64", product_ns(precision), "cuda")
+    finally:
+        pk.set_deterministic(False)
+    diff = [k for k in a if not torch.equal(a[k], b[k])]
+    assert not diff, diff

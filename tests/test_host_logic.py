@@ -26,7 +26,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert declared == set(_hip.SIGNATURES), declared ^ set(_hip.SIGNATURES)
     lib = _hip.lib()
     ops = _hip.ops()  # the TORCH_LIBRARY shim over the same ABI: one o2m:: op per launcher
-    for name in _hip.SIGNATURES:
+    for name in set(_hip.SIGNATURES) - _hip.MEASUREMENT_ONLY:  # (the launch timer is host-side bookkeeping, not an operator)
         assert hasattr(ops, name[len("o2m_"):]), name
     for name in declared:
         assert hasattr(lib, name), name

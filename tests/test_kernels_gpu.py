@@ -394,3 +394,49 @@ def test_c_abi_rejects_bad_arguments_of_the_widened_entry_points():
     with pytest.raises(RuntimeError, match="come together"):  # q and qt come as a pair
         H.prepare_weights(w, torch.empty(8, 3, 3, 8, device=dev), torch.empty(8, 3, 3, 8, device=dev, dtype=torch.bfloat16),
                           torch.empty(8, 3, 3, 8, device=dev, dtype=torch.bfloat16), torch.empty(8, 8, device=dev), None, 0.1)
+
+
+@pytest.mark.gpu
+def test_channel_sums_deterministic_mode_is_bitwise_reproducible_and_matches_atomics():
+    """deterministic_cuda_kernels (reference train.py:41-45): act_bwd_reduce / fold_scale_dot add their
+    per-chunk rows in chunk order instead of with fp32 atomics.  Same numbers as the atomic form to fp32
+    rounding, identical bits from launch to launch; the latent gradient of style_bwd has one fixed-order
+    form in both modes."""
+    from one_to_many_gan_amd import _hip as H
+
+    torch.manual_seed(5)
+    B, S, C = 16, 64, 256
+    g = torch.randn(B, S, S, C, device="cuda").to(torch.bfloat16)
+    y = torch.randn(B, S, S, C, device="cuda").to(torch.bfloat16)
+    x = torch.randn(B, S, S, C, device="cuda").to(torch.bfloat16)
+    scale = torch.rand(B, C, device="cuda") + 0.5
+
+    def run():
+        sums = torch.zeros(B, 2, C, device="cuda")
+        dots = torch.zeros(B, C, device="cuda")
+        gu, gx = torch.empty_like(g), torch.empty_like(g)
+        H.act_bwd_reduce(g, y, None, None, gu, sums, H.ACT_LRELU)
+        H.fold_scale_dot(g, x, scale, gx, dots, 0)
+        return sums, dots, gu, gx
+
+    assert not H.DETERMINISTIC
+    ref = run()
+    H.DETERMINISTIC = True
+    try:
+        a, b = run(), run()
+        # accumulation semantics: a second launch ADDS to sums
+        twice = a[0].clone()
+        H.act_bwd_reduce(g, y, None, None, torch.empty_like(g), twice, H.ACT_LRELU)
+    finally:
+        H.DETERMINISTIC = False
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    for u, v in zip(a, ref):
+        assert float((u.float() - v.float()).abs().max()) <= 2e-5 * float(v.float().abs().max())
+    assert float((twice - 2 * a[0]).abs().max()) <= 1e-6 * float(a[0].abs().max())
+    # exact values: fp64 sums of the same bf16 operands
+    d = g.double() * torch.where(y > 0, 1.0, 0.2).double()
+    want0 = d.sum(dim=(1, 2))
+    assert float((a[0][:, 0].double() - want0).abs().max()) <= 1e-5 * float(want0.abs().max())
+    want_dots = (g.double() * x.double()).sum(dim=(1, 2))
+    assert float((a[1].double() - want_dots).abs().max()) <= 1e-5 * float(want_dots.abs().max())

@@ -15,7 +15,7 @@ def _meta(*shape, dtype=torch.bfloat16):
 
 def test_every_launcher_has_a_schema_with_mutable_outputs():
     ops = _hip.ops()
-    for name in _hip.SIGNATURES:
+    for name in set(_hip.SIGNATURES) - _hip.MEASUREMENT_ONLY:
         op = getattr(ops, name[len("o2m_"):]).default
         assert op._schema.name == "o2m::" + name[len("o2m_"):]
     s = ops.conv2d_fwd.default._schema
