@@ -69,22 +69,34 @@ __device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
   *reinterpret_cast<f32x4*>(p + 4) = b;
 }
 
-__device__ __forceinline__ float act_fwd(float v, int act) {
-  switch (act) {
-    case O2M_ACT_RELU: return v > 0.f ? v : 0.f;
-    case O2M_ACT_LRELU: return v > 0.f ? v : 0.2f * v;
-    case O2M_ACT_TANH: return tanhf(v);
-    default: return v;
-  }
+// The activation code is uniform over a launch.  A per-element `switch` compiles into a chain of scalar
+// compare-and-branch blocks PER ELEMENT (with the tanh expansion in the middle): measured 8 of the 11 us
+// the p8 igemm's epilogue took.  So: ReLU / LeakyReLU / identity are one select each, driven by two
+// uniform values, and tanh sits behind ONE uniform branch per call (act_fwd8: per 8 values).
+__device__ __forceinline__ float act_fwd_piecewise(float v, bool relu, float neg) {
+  return v > 0.f ? v : (relu ? 0.f : v * neg);
 }
-// derivative expressed through the activation OUTPUT y
-__device__ __forceinline__ float act_bwd_from_out(float y, int act) {
-  switch (act) {
-    case O2M_ACT_RELU: return y > 0.f ? 1.f : 0.f;
-    case O2M_ACT_LRELU: return y > 0.f ? 1.f : 0.2f;
-    case O2M_ACT_TANH: return 1.f - y * y;
-    default: return 1.f;
+__device__ __forceinline__ float act_fwd(float v, int act) {
+  if (act == O2M_ACT_TANH) return tanhf(v);
+  return act_fwd_piecewise(v, act == O2M_ACT_RELU, act == O2M_ACT_LRELU ? 0.2f : 1.f);
+}
+__device__ __forceinline__ void act_fwd8(float (&v)[8], int act) {
+  if (act == O2M_ACT_NONE) return;
+  if (act == O2M_ACT_TANH) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = tanhf(v[q]);
+    return;
   }
+  const bool relu = act == O2M_ACT_RELU;
+  const float neg = act == O2M_ACT_LRELU ? 0.2f : 1.f;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) v[q] = act_fwd_piecewise(v[q], relu, neg);
+}
+// derivative expressed through the activation OUTPUT y (branch-free: selects on uniform values)
+__device__ __forceinline__ float act_bwd_from_out(float y, int act) {
+  const float neg = act == O2M_ACT_RELU ? 0.f : (act == O2M_ACT_LRELU ? 0.2f : 1.f);
+  const float piece = y > 0.f ? 1.f : neg;
+  return act == O2M_ACT_TANH ? 1.f - y * y : piece;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -492,6 +492,28 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
   const T* __restrict__ R = static_cast<const T*>(d.residual);
   constexpr int VPR = BN / 8;  // 8-channel vectors per row
   const int act = d.act;
+  // read-out: a thread keeps ONE 8-channel vector (NT % VPR == 0) and walks rows NT / VPR apart; its bias and
+  // (tile inside one sample) demodulation scale are loaded once, ahead of the passes, instead of per row
+  static_assert(NT % VPR == 0 && (WM * VPR) % NT == 0, "one channel vector per thread");
+  constexpr int RPI = NT / VPR;  // rows per iteration
+  const int ec8 = tid % VPR, erow = tid / VPR, en = n0 + ec8 * 8;
+  const bool ecol_ok = en < Co;
+  float esc[8], ebias[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { esc[q] = 1.f; ebias[q] = 0.f; }
+  if (ecol_ok) {
+    if (d.out_scale && b_uniform) {
+      const float* sp = d.out_scale + (size_t)b_first * Co + en;
+      const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 4);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { esc[q] = s0[q]; esc[4 + q] = s1[q]; }
+    }
+    if (d.bias) {
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(d.bias + en), b1 = *reinterpret_cast<const f32x4*>(d.bias + en + 4);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { ebias[q] = b0[q]; ebias[4 + q] = b1[q]; }
+    }
+  }
 #pragma unroll 1
   for (int pass = 0; pass < WAVES_M; ++pass) {
     if (pass == wave / WAVES_N) {
@@ -508,34 +530,31 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
     float st[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) st[q] = 0.f;
-#pragma unroll 1
-    for (int v = tid; v < WM * VPR; v += NT) {
-      const int row = v / VPR, c8 = v - row * VPR;
-      const int m = mbase + row, n = n0 + c8 * 8;
-      if (m >= M || n >= Co) continue;
-      const f32x4 a = *reinterpret_cast<const f32x4*>(csm + row * CSTR + c8 * 8);
-      const f32x4 b = *reinterpret_cast<const f32x4*>(csm + row * CSTR + c8 * 8 + 4);
+#pragma unroll 4
+    for (int it = 0; it < WM / RPI; ++it) {
+      const int row = erow + it * RPI;
+      const int m = mbase + row;
+      if (m >= M || !ecol_ok) continue;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(csm + row * CSTR + ec8 * 8);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(csm + row * CSTR + ec8 * 8 + 4);
       float o[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-      if (d.out_scale) {
-        const float* sp = d.out_scale + (size_t)(b_uniform ? b_first : m / HoWo) * Co + n;
+      if (d.out_scale && !b_uniform) {
+        const float* sp = d.out_scale + (size_t)(m / HoWo) * Co + en;
         const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 4);
 #pragma unroll
         for (int q = 0; q < 4; ++q) { o[q] *= s0[q]; o[4 + q] *= s1[q]; }
-      }
-      if (d.bias) {
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(d.bias + n), b1 = *reinterpret_cast<const f32x4*>(d.bias + n + 4);
+      } else if (d.out_scale) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { o[q] += b0[q]; o[4 + q] += b1[q]; }
+        for (int q = 0; q < 8; ++q) o[q] *= esc[q];
       }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) o[q] += ebias[q];
       if (d.stats) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) { st[q] += o[q]; st[8 + q] += o[q] * o[q]; }
       }
-      if (act != O2M_ACT_NONE) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) o[q] = act_fwd(o[q], act);
-      }
-      const size_t off = (size_t)m * Co + n;
+      act_fwd8(o, act);
+      const size_t off = (size_t)m * Co + en;
       if (R) {
         float rv[8];
         load8(R + off, rv);
@@ -611,6 +630,15 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 // a phase, summed per wave in scalar registers; never compiled into libo2m_hip.so.
 #ifdef O2M_P8_STAMPS
 __device__ unsigned long long o2m_p8_stamps[2][8];
+__device__ unsigned long long o2m_p8_estamps[2][12];  // epilogue timeline (absolute s_memtime values)
+#define P8_ESTAMP(i)                                                                       \
+  do {                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                     \
+    unsigned long long t_;                                                                 \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+    __builtin_amdgcn_sched_barrier(0);                                                     \
+    if (blockIdx.x == 7 && (wave == 0 || wave == 4) && lane == 0) o2m_p8_estamps[wave >> 2][i] = t_; \
+  } while (0)
 #define P8_STAMP(i)                                                                        \
   do {                                                                                     \
     __builtin_amdgcn_sched_barrier(0);                                                     \
@@ -622,6 +650,7 @@ __device__ unsigned long long o2m_p8_stamps[2][8];
   } while (0)
 #else
 #define P8_STAMP(i) do {} while (0)
+#define P8_ESTAMP(i) do {} while (0)
 #endif
 
 // FMT: element format of the MFMA operands.  0 = bf16 (x, w, y bf16: v_mfma_f32_16x16x32_bf16).
@@ -832,6 +861,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
   } while (0)
 
   // ---- prologue: regions needed by phases -1 .. 4 -------------------------------------------------------
+  P8_ESTAMP(0);
   issue_b(0);  // B0(0)
   issue_a(0);  // A0(0)
   issue_b(1);  // B1(0)
@@ -885,9 +915,11 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
     for (int i = 0; i < 8; ++i) o2m_p8_stamps[wave >> 2][i] = st_sum[i];
   }
 #endif
+  P8_ESTAMP(1);
   if (wrow == 0) __builtin_amdgcn_s_barrier();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the zero fills issued past the end of the reduction
   __syncthreads();
+  P8_ESTAMP(2);
 
   // ---- epilogue: fp32 tile through LDS, whole channel vectors out (as in conv_igemm_kernel) -------------
   constexpr int CSTR = BN + 4;
@@ -897,6 +929,25 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
   constexpr int VPR = BN / 8;
   const int act = d.act;
   const float deq = (FMT != 0 && d.deq_scale) ? d.deq_scale[0] * d.deq_scale[2] : 1.f;  // {1/scale, amax} of x, of w
+  static_assert(NT % VPR == 0, "one channel vector per thread");
+  const int ec8 = tid % VPR, erow = tid / VPR, en = n0 + ec8 * 8;
+  const bool ecol_ok = en < Co;
+  float esc[8], ebias[8];  // multiplier (dequantisation x demodulation of a one-sample tile) and bias of this thread's channels
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { esc[q] = deq; ebias[q] = 0.f; }
+  if (ecol_ok) {
+    if (d.out_scale && b_uniform) {
+      const float* sp = d.out_scale + (size_t)b_first * Co + en;
+      const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 4);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { esc[q] *= s0[q]; esc[4 + q] *= s1[q]; }
+    }
+    if (d.bias) {
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(d.bias + en), b1 = *reinterpret_cast<const f32x4*>(d.bias + en + 4);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { ebias[q] = b0[q]; ebias[4 + q] = b1[q]; }
+    }
+  }
 #pragma unroll 1
   for (int pass = 0; pass < 2; ++pass) {
     if (pass == wrow) {
@@ -909,53 +960,54 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
           for (int r = 0; r < 4; ++r)
             csm[(i * 16 + 4 * (lane >> 4) + r) * CSTR + wcol * 64 + j * 16 + (lane & 15)] = acc[i][j][r];
     }
+    if (pass == 0) P8_ESTAMP(3); else P8_ESTAMP(7);
     __syncthreads();
+    if (pass == 0) P8_ESTAMP(4); else P8_ESTAMP(8);
     const int mbase = m0 + pass * 128;
     float st[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) st[q] = 0.f;
-#pragma unroll 1
-    for (int v = tid; v < 128 * VPR; v += NT) {
-      const int row = v / VPR, c8 = v - row * VPR;
-      const int m = mbase + row, n = n0 + c8 * 8;
-      if (m >= M || n >= Co) continue;
-      const f32x4 a = *reinterpret_cast<const f32x4*>(csm + row * CSTR + c8 * 8);
-      const f32x4 b = *reinterpret_cast<const f32x4*>(csm + row * CSTR + c8 * 8 + 4);
+    // A thread keeps ONE 8-channel vector (NT % VPR == 0) and walks 8 rows, 16 apart: bias and (for a tile
+    // inside one sample) the demodulation scale are loaded once, ahead of the loop, and the loop is unrolled
+    // so that its LDS reads, residual loads and stores overlap.  (Measured before: the epilogue cost 11.3 of
+    // the canonical layer's 78 us -- every iteration waited for its own bias / scale loads from L2.)
+#pragma unroll 4
+    for (int it = 0; it < 128 / (NT / VPR); ++it) {
+      const int row = erow + it * (NT / VPR);
+      const int m = mbase + row;
+      if (m >= M || !ecol_ok) continue;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(csm + row * CSTR + ec8 * 8);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(csm + row * CSTR + ec8 * 8 + 4);
       float o[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-      if constexpr (FMT != 0) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) o[q] *= deq;
-      }
-      if (d.out_scale) {
-        const float* sp = d.out_scale + (size_t)(b_uniform ? b_first : m / HoWo) * Co + n;
+      if (d.out_scale && !b_uniform) {
+        const float* sp = d.out_scale + (size_t)(m / HoWo) * Co + en;
         const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 4);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { o[q] *= s0[q]; o[4 + q] *= s1[q]; }
-      }
-      if (d.bias) {
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(d.bias + n), b1 = *reinterpret_cast<const f32x4*>(d.bias + n + 4);
+        for (int q = 0; q < 4; ++q) { o[q] *= s0[q] * deq; o[4 + q] *= s1[q] * deq; }
+      } else {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { o[q] += b0[q]; o[4 + q] += b1[q]; }
+        for (int q = 0; q < 8; ++q) o[q] *= esc[q];
       }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) o[q] += ebias[q];
       if (d.stats) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) { st[q] += o[q]; st[8 + q] += o[q] * o[q]; }
       }
-      if (act != O2M_ACT_NONE) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) o[q] = act_fwd(o[q], act);
-      }
-      const size_t off = (size_t)m * Co + n;
+      act_fwd8(o, act);
+      const size_t off = (size_t)m * Co + en;
       if (R) {
         float rv[8];
         load8(R + off, rv);
 #pragma unroll
         for (int q = 0; q < 8; ++q) o[q] += rv[q];
       }
-      store8(Y + off, o);
+            store8(Y + off, o);
     }
     if (d.stats && mbase < M) stats_block_reduce<NT, VPR>(st, csm, d.stats, (long)(mbase / 128), n0, Co, tid);
+    if (pass == 0) P8_ESTAMP(5); else P8_ESTAMP(9);
     if (pass == 0) __syncthreads();
+    if (pass == 0) P8_ESTAMP(6);
   }
 }
 
@@ -1062,6 +1114,9 @@ static int stats_rows_for(const o2m_conv_desc& d) {
 }
 
 #ifdef O2M_P8_STAMPS
+extern "C" int o2m_debug_estamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(o2m_p8_estamps), sizeof(unsigned long long) * 24);
+}
 extern "C" int o2m_debug_stamps(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(o2m_p8_stamps), sizeof(unsigned long long) * 16);
 }

@@ -301,16 +301,22 @@ __global__ __launch_bounds__(NT) void in_apply_kernel(const T* __restrict__ x, c
     for (int u = 0; u < U; ++u) {
       const int p = p0 + u * gm.PL;
       if (p >= pe) continue;
-      float ov[8];
+      float ov[8], xh[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float xh = (xv[u][i] - mean[i]) * rstd[i];
-        if (MODE == 0) {
-          const float t = act_fwd(xh, act);
-          ov[i] = res ? t + sv[u][i] : t;
-        } else {
-          const float gh = sv[u][i] * act_bwd_from_out(xh, act);
-          ov[i] = rstd[i] * (gh - m1[i] - xh * m2[i]);
+      for (int i = 0; i < 8; ++i) xh[i] = (xv[u][i] - mean[i]) * rstd[i];
+      if (MODE == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ov[i] = xh[i];
+        act_fwd8(ov, act);  // one dispatch per vector (common.h)
+        if (res) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) ov[i] += sv[u][i];
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float gh = sv[u][i] * act_bwd_from_out(xh[i], act);
+          ov[i] = rstd[i] * (gh - m1[i] - xh[i] * m2[i]);
         }
       }
       store8(out + ((size_t)b * P + p) * C + cv * 8, ov);

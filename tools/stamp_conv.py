@@ -22,3 +22,14 @@ nph = 36 * 4
 for g in range(2):
     a = v[g * 8: g * 8 + 6]
     print(f"wave row {g}: cycles per PHASE: " + "  ".join(f"{n} {c / nph:.0f}" for n, c in zip(names, a)) + f"  total {sum(a) / nph:.0f}")
+
+# epilogue timeline (absolute s_memtime values of waves 0 and 4 of block 7)
+ebuf = (ctypes.c_ulonglong * 24)()
+H.lib().o2m_debug_estamps.argtypes = [ctypes.c_void_p]
+print("rc", H.lib().o2m_debug_estamps(ebuf))
+ev = list(ebuf)
+labels = ["kernel start", "main loop done", "fills drained + sync", "pass0 tile written", "pass0 barrier", "pass0 read-out done",
+          "pass0 closing barrier", "pass1 tile written", "pass1 barrier", "pass1 read-out done"]
+for g in range(2):
+    t = ev[g * 12: g * 12 + 10]
+    print(f"wave row {g}: " + "  ".join(f"{n} +{t[i] - t[i - 1] if i else 0}" for i, n in enumerate(labels)))
