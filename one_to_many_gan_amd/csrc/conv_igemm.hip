@@ -101,6 +101,14 @@ __device__ __forceinline__ void stg_to_lds(const Stg<T>& s, const f32x4 (&sc)[2]
   }
 }
 
+// Barrier that orders LDS traffic only.  __syncthreads() also waits for this wave's outstanding GLOBAL stores
+// (vmcnt(0)); between the epilogue passes that would park every wave until the previous pass's output rows
+// have reached memory, although the next pass only reuses the LDS staging tile.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
 // InstanceNorm partial sums from the epilogue (o2m_conv_desc.stats).  Every thread of the read-out
 // loop keeps ONE 8-channel vector (NT % (BN/8) == 0) and walks rows, so it sums its rows in
 // registers; the NT / VPR threads that share a vector are then added through LDS (the staged tile
@@ -109,10 +117,10 @@ __device__ __forceinline__ void stg_to_lds(const Stg<T>& s, const f32x4 (&sc)[2]
 template <int NT, int VPR>
 __device__ __forceinline__ void stats_block_reduce(const float (&st)[16], float* red, float* __restrict__ stats,
                                                    long part, int n0, int Co, int tid) {
-  __syncthreads();  // every thread has finished reading the staged tile
+  lds_barrier();  // every thread has finished reading the staged tile
 #pragma unroll
   for (int q = 0; q < 16; ++q) red[q * NT + tid] = st[q];
-  __syncthreads();
+  lds_barrier();
   if (tid < VPR * 16) {
     const int c8 = tid % VPR, q = tid / VPR;
     float s = 0.f;
@@ -525,7 +533,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
           for (int r = 0; r < 16; ++r)
             csm[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * CSTR + wn + j * 32 + lr] = acc[i][j][r];
     }
-    __syncthreads();
+    lds_barrier();
     const int mbase = m0 + pass * WM;
     float st[16];
 #pragma unroll
@@ -567,7 +575,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
       if constexpr (NT % VPR == 0 && VPR * 16 <= NT)
         stats_block_reduce<NT, VPR>(st, csm, d.stats, (long)(mbase / WM), n0, Co, tid);
     }
-    if (pass + 1 < WAVES_M) __syncthreads();
+    if (pass + 1 < WAVES_M) lds_barrier();
   }
 }
 
@@ -961,7 +969,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
             csm[(i * 16 + 4 * (lane >> 4) + r) * CSTR + wcol * 64 + j * 16 + (lane & 15)] = acc[i][j][r];
     }
     if (pass == 0) P8_ESTAMP(3); else P8_ESTAMP(7);
-    __syncthreads();
+    lds_barrier();
     if (pass == 0) P8_ESTAMP(4); else P8_ESTAMP(8);
     const int mbase = m0 + pass * 128;
     float st[16];
@@ -1006,7 +1014,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
     }
     if (d.stats && mbase < M) stats_block_reduce<NT, VPR>(st, csm, d.stats, (long)(mbase / 128), n0, Co, tid);
     if (pass == 0) P8_ESTAMP(5); else P8_ESTAMP(9);
-    if (pass == 0) __syncthreads();
+    if (pass == 0) lds_barrier();
     if (pass == 0) P8_ESTAMP(6);
   }
 }
