@@ -46,7 +46,9 @@ __device__ __forceinline__ void lanes_reduce(float (&v)[NV], int cv, int pl, int
 }
 
 // ---- act backward + per-(b,c) sums --------------------------------------------------------
-template <typename T>
+// HAS_Y / HAS_RES: which operands exist is a property of the launch; as run-time pointer tests inside the
+// 8-element loop they compiled into two uniform branches per ELEMENT.
+template <typename T, bool HAS_Y, bool HAS_RES>
 __global__ __launch_bounds__(NT) void act_bwd_reduce_kernel(const T* __restrict__ g, const T* __restrict__ y,
                                                             const T* __restrict__ res,
                                                             const float* __restrict__ out_mul,
@@ -68,13 +70,13 @@ __global__ __launch_bounds__(NT) void act_bwd_reduce_kernel(const T* __restrict_
       const size_t o = ((size_t)b * P + p) * C + cv * 8;
       float gv[8], yv[8], rv[8], ov[8];
       load8(g + o, gv);
-      if (y) load8(y + o, yv);
-      if (res) load8(res + o, rv);
+      if constexpr (HAS_Y) load8(y + o, yv);
+      if constexpr (HAS_RES) load8(res + o, rv);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        // y == nullptr: reduce-only call (identity activation), sums[.][1] stays 0
-        float u = y ? (res ? yv[i] - rv[i] : yv[i]) : 0.f;
-        float d = y ? gv[i] * act_bwd_from_out(u, act) : gv[i];
+        // no y: reduce-only call (identity activation), sums[.][1] stays 0
+        const float u = HAS_Y ? (HAS_RES ? yv[i] - rv[i] : yv[i]) : 0.f;
+        const float d = HAS_Y ? gv[i] * act_bwd_from_out(u, act) : gv[i];
         ov[i] = d * mul[i];
         acc[i] += d;
         acc[8 + i] += d * u;
@@ -868,9 +870,14 @@ int o2m_act_bwd_reduce(const void* g, const void* y, const void* residual, const
   ChanGeom gm = chan_geom(B, P, C);
   const size_t lds = (size_t)gm.PL * gm.CV * 16 * sizeof(float);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(act_bwd_reduce_kernel<T>, dim3(gm.nchunks, B), dim3(NT), lds, s,
-                                       (const T*)g, (const T*)y, (const T*)residual, out_mul, (T*)gu,
-                                       sums, partials, P, C, act, gm));
+#define O2M_ABR(HY, HR)                                                                                   \
+  DISPATCH_T(dtype, hipLaunchKernelGGL((act_bwd_reduce_kernel<T, HY, HR>), dim3(gm.nchunks, B), dim3(NT), lds, s, \
+                                       (const T*)g, (const T*)y, (const T*)residual, out_mul, (T*)gu, sums,     \
+                                       partials, P, C, act, gm))
+  if (!y) { O2M_ABR(false, false); }
+  else if (!residual) { O2M_ABR(true, false); }
+  else { O2M_ABR(true, true); }
+#undef O2M_ABR
   O2M_LAUNCH_CHECK();
   if (partials) {
     hipLaunchKernelGGL(chunk_sum_kernel, dim3(B), dim3(NT), 0, s, sums, partials, gm.nchunks, 2 * C);
