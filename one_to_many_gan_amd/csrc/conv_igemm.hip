@@ -101,6 +101,14 @@ __device__ __forceinline__ void stg_to_lds(const Stg<T>& s, const f32x4 (&sc)[2]
   }
 }
 
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
+constexpr int lds_bytes() {
+  constexpr bool F32 = sizeof(T) == 4;
+  constexpr int lds_main = (F32 ? 2 : 1) * (F32 ? 1 : 2) * (BM + BN) * BK * 2;
+  constexpr int lds_epi = (BM / WAVES_M) * (BN + 4) * 4;
+  return lds_main > lds_epi ? lds_main : lds_epi;
+}
+
 // Barrier that orders LDS traffic only.  __syncthreads() also waits for this wave's outstanding GLOBAL stores
 // (vmcnt(0)); between the epilogue passes that would park every wave until the previous pass's output rows
 // have reached memory, although the next pass only reuses the LDS staging tile.
@@ -522,24 +530,36 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
       for (int q = 0; q < 4; ++q) { ebias[q] = b0[q]; ebias[4 + q] = b1[q]; }
     }
   }
+  // Passes: as many wave rows at a time as the (now idle) stage buffers hold -- all of a 256x64 / 128x64 /
+  // 256x32 tile in ONE pass, two wave rows of a 256x128 tile -- so the staging writes of several wave rows run
+  // in parallel and there are fewer barriers.  With InstanceNorm partials (one per wave row of pixels, the
+  // granularity o2m_conv2d_stats_rows reports) it stays one wave row per pass.
+  constexpr int LDS_TOTAL = lds_bytes<T, BM, BN, WAVES_M, WAVES_N>();
+  constexpr int WPP_MAX = (LDS_TOTAL / (CSTR * 4) / WM) >= WAVES_M ? WAVES_M
+                          : ((LDS_TOTAL / (CSTR * 4) / WM) >= 2 && WAVES_M % 2 == 0 ? 2 : 1);
+  const int wpp = d.stats ? 1 : WPP_MAX;  // wave rows per pass
+  const int npass = WAVES_M / wpp;
+  const int wrow_ = wave / WAVES_N;
 #pragma unroll 1
-  for (int pass = 0; pass < WAVES_M; ++pass) {
-    if (pass == wave / WAVES_N) {
+  for (int pass = 0; pass < npass; ++pass) {
+    if (wrow_ / wpp == pass) {
+      float* dst = csm + (wrow_ % wpp) * WM * CSTR;
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int r = 0; r < 16; ++r)
-            csm[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * CSTR + wn + j * 32 + lr] = acc[i][j][r];
+            dst[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * CSTR + wn + j * 32 + lr] = acc[i][j][r];
     }
     lds_barrier();
-    const int mbase = m0 + pass * WM;
+    const int mbase = m0 + pass * wpp * WM;
     float st[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) st[q] = 0.f;
+    const int iters = wpp * (WM / RPI);
 #pragma unroll 4
-    for (int it = 0; it < WM / RPI; ++it) {
+    for (int it = 0; it < iters; ++it) {
       const int row = erow + it * RPI;
       const int m = mbase + row;
       if (m >= M || !ecol_ok) continue;
@@ -575,16 +595,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
       if constexpr (NT % VPR == 0 && VPR * 16 <= NT)
         stats_block_reduce<NT, VPR>(st, csm, d.stats, (long)(mbase / WM), n0, Co, tid);
     }
-    if (pass + 1 < WAVES_M) lds_barrier();
+    if (pass + 1 < npass) lds_barrier();
   }
-}
-
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
-constexpr int lds_bytes() {
-  constexpr bool F32 = sizeof(T) == 4;
-  constexpr int lds_main = (F32 ? 2 : 1) * (F32 ? 1 : 2) * (BM + BN) * BK * 2;
-  constexpr int lds_epi = (BM / WAVES_M) * (BN + 4) * 4;
-  return lds_main > lds_epi ? lds_main : lds_epi;
 }
 
 inline long out_rows(const o2m_conv_desc& d) {
