@@ -338,17 +338,19 @@ def main():
     if flop:
         out["step_mfma_frac"] = round(images_per_sec * flop / (world * MFMA_PEAK[args.precision]), 4)
         out["algorithmic_tflops_per_gpu"] = round(images_per_sec * flop / world / 1e12, 2)
-    if rank == 0 and not args.no_kernel_profile:
-        for r in reducers:  # the extra profiled step runs on rank 0 alone: no collectives
-            r.enabled = False
-        trainer.kl_hook = None
-        out["roofline"] = kernel_profile(trainer, args.precision)
-    if world > 1:
-        dist.barrier()
-    if args.dump_params:
+    if args.dump_params:  # (before rank 0 takes its extra, unsynchronised timer steps)
         sums = [float(o.bucket.flat.double().sum()) for o in (trainer.oD, trainer.oG, trainer.oM, trainer.oS)]
         with open(f"{args.dump_params}.rank{rank}", "w") as f:
             json.dump(sums, f)
+    if rank == 0 and not args.no_kernel_profile:
+        for r in reducers:  # the extra profiled steps run on rank 0 alone: no collectives of any kind
+            r.enabled = False
+        trainer.kl_hook = None
+        if world > 1:
+            trainer.ada_p.update_p = trainer.ada_p.local_update_p  # undo dist.sync_ada_p's all-reduce
+        out["roofline"] = kernel_profile(trainer, args.precision)
+    if world > 1:
+        dist.barrier()
     if rank == 0 and world == 1 and not args.no_parity_mode and args.precision == "bf16":
         del trainer
         torch.cuda.empty_cache()

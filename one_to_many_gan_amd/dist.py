@@ -155,4 +155,5 @@ def sync_ada_p(ada_p, group=None):
         local_update(score / world)
 
     ada_p.update_p = update_p
+    ada_p.local_update_p = local_update  # the unsynchronised controller (a rank working alone: bench.py's timer steps)
     return ada_p

@@ -22,12 +22,15 @@ def test_two_ranks_stay_in_lockstep(tmp_path):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", "29611", os.path.join(ROOT, "bench.py"),
            "--gpus", "2", "--steps", "3", "--warmup", "1", "--size", "64", "--batch", "2",
-           "--no-cpu-baseline", "--no-kernel-profile", "--dump-params", dump]
+           "--no-cpu-baseline", "--dump-params", dump]  # with the roofline leg: rank 0 then works alone
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=500)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["value"] > 0
+    # the per-kernel timer steps run on rank 0 alone while rank 1 waits at the barrier: they must not issue a
+    # collective (gradient reducers, KL hook and the ADAp score sync are all switched off for them)
+    assert out["roofline"]["kernel"].startswith("conv_")
     a = json.load(open(dump + ".rank0"))
     b = json.load(open(dump + ".rank1"))
     # different data per rank, identical weights after 4 synchronised optimiser steps
