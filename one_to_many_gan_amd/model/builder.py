@@ -113,6 +113,8 @@ class Generator(nn.Module):
 
     def _decode(self, t, w, collect: bool):
         feats, i = [], 0
+        # one UnbindBackward (a single stack) instead of a zeros + copy + accumulate trio per style block
+        w = w.unbind(0)
         for m in self.decoder:
             if isinstance(m, ModulatedResnetBlock):
                 t = m.run(t, w[i])

@@ -247,10 +247,8 @@ class PreparedWeight:
             kk = k + r - 1
             nco = pad8(r * r * self.co)
             w2 = torch.zeros((nco, kk, kk, self.cip), dtype=torch.float32, device=full.device)
-            for dy in range(r):
-                for dx in range(r):
-                    o0 = (dy * r + dx) * self.co
-                    w2[o0: o0 + self.co, dy: dy + k, dx: dx + k, :] = full[: self.co]
+            # w2[(dy, dx, co), dy + a, dx + b, :] = full[co, a, b, :] for the 16 block offsets: ONE strided copy
+            self._s2d_blocks(w2).copy_(full[: self.co].expand(r, r, self.co, k, k, self.cip))
             self._s2d_val = w2.to(compute_dtype()).contiguous()
             self._s2d_key = key
         return self._s2d_val
@@ -274,13 +272,18 @@ class PreparedWeight:
     def fold_s2d(self):
         """dW[co, kh, kw] = sum over the 16 block offsets of dW2[(dy, dx, co), kh + dy, kw + dx]
         (the adjoint of s2d_weights)."""
-        r, k = self.S2D, self.kh
-        for dy in range(r):
-            for dx in range(r):
-                o0 = (dy * r + dx) * self.co
-                self.dw_acc[: self.co] += self.dw2_acc[o0: o0 + self.co, dy: dy + k, dx: dx + k, :]
+        self.dw_acc[: self.co] += self._s2d_blocks(self.dw2_acc).sum(dim=(0, 1))
         self.dw2_acc.zero_()
         self.dw2_used = False
+
+    def _s2d_blocks(self, w2):
+        """View of a [(dy, dx, co), k + 3, k + 3, cip] space-to-depth filter as [dy, dx, co, a, b, cip] with
+        element (dy, dx, co, a, b) at tap (dy + a, dx + b): the 16 shifted copies of the k x k filter."""
+        r, k = self.S2D, self.kh
+        kk = k + r - 1
+        sa, sb = kk * self.cip, self.cip  # strides of the two tap dimensions
+        sco = kk * kk * self.cip
+        return w2.as_strided((r, r, self.co, k, k, self.cip), (r * self.co * sco + sa, self.co * sco + sb, sco, sa, sb, 1))
 
     def get(self):
         w = self.weight
