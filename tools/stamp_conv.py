@@ -1,5 +1,11 @@
-"""Diagnostic only: reads the s_memtime segment stamps of the stamped p8 igemm build
-(build/variants/p8stamp.so, compiled with -DO2M_P8_STAMPS).  Run with O2M_HIP_LIB=build/variants/p8stamp.so."""
+"""Diagnostic only: reads the s_memtime segment stamps of the stamped p8 igemm build.
+
+  mkdir -p build/variants && cd one_to_many_gan_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC \
+      -munsafe-fp-atomics -DO2M_P8_STAMPS -shared conv_igemm.hip conv_wgrad.hip pointwise.hip style.hip ada.hip \
+      -o ../../build/variants/p8stamp.so
+  O2M_HIP_LIB=build/variants/p8stamp.so python tools/stamp_conv.py
+
+Prints the cycles per phase segment (fill issue, waits, MFMAs, barriers) and the epilogue timeline of two waves."""
 import os, sys, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
