@@ -67,3 +67,29 @@ def test_ops_trace_under_fake_tensor_mode():
         ops.instnorm_apply(y, mr, None, torch.empty_like(y), _hip.ACT_RELU)
         p = torch.empty(128, device="cuda")
         ops.adam_step(p, p.clone(), p.clone(), p.clone(), torch.empty(1, device="cuda"), 1e-3, 0.5, 0.99, 1e-8, 1.0)
+
+
+def test_every_launch_goes_through_the_device_guard_and_train_selects_its_device():
+    """with gpu_number != 0 a launch on torch's default stream (handle 0) would bind to device 0
+    while its pointers live on device N.  Host-side check of the two places that prevent it: every
+    launcher call in the operator shim sits inside O2M_CALL (which builds `Launch`: c10::DeviceGuard on
+    the tensor's device + that device's current stream), and train.py selects its device before building
+    anything."""
+    import os
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shim = open(os.path.join(root, "one_to_many_gan_amd", "csrc", "torch_ops.cpp")).read()
+    assert re.search(r"struct Launch \{[^}]*c10::DeviceGuard guard;", shim, re.S)
+    assert "getCurrentHIPStreamMasqueradingAsCUDA" in shim and "Launch L(t);" in shim
+    # launcher symbols that take a stream appear nowhere outside an O2M_CALL(...) argument
+    launchers = [n for n, (_, a) in _hip.SIGNATURES.items() if a and a[-1] is _hip._vp and n not in _hip.MEASUREMENT_ONLY]
+    assert len(launchers) >= 25
+    body = shim[shim.index("#define O2M_CALL"):]
+    for name in launchers:
+        for m in re.finditer(r"\b" + name + r"\(", body):
+            before = body[max(0, m.start() - 200): m.start()]
+            assert "O2M_CALL(" in before, name
+    train = open(os.path.join(root, "train.py")).read()
+    run_src = train[train.index("def run("):]
+    assert run_src.index("torch.cuda.set_device(device)") < run_src.index("Generator(")
