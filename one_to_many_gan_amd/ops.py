@@ -191,7 +191,7 @@ class PreparedWeight:
         the end of backward: finalise the layer, so the data-parallel reducer can start the bucket
         segment's all-reduce under the rest of backward (dist.BucketReducer)."""
         self.bwd_uses += 1
-        if self.bwd_uses == self.fwd_uses and _EARLY_FINALIZE:
+        if self.bwd_uses == self.fwd_uses and _early_finalize():
             wst = _wgrad_stream(device)
             if wst is not None:
                 torch.cuda.current_stream(device).wait_stream(wst)
@@ -311,9 +311,12 @@ import os as _os
 # alive until the end of backward, so it is off by default.
 _DEFER_WGRAD = _os.environ.get("O2M_DEFER_WGRAD", "0") == "1"
 # The style-path kernels are B x C sized: alone on the GPU they leave 250 CUs idle for 6-14 us each
-# (~110 launches per generator backward).  O2M_SIDE_STREAM=1 (default) runs them on a second HIP
-# stream, ordered by events, so they overlap the neighbouring convolution kernels.
-_SIDE_STREAM = _os.environ.get("O2M_SIDE_STREAM", "1") == "1"
+# (~110 launches per generator backward).  O2M_SIDE_STREAM=1 runs them on a second HIP stream, ordered by
+# events, so they overlap the neighbouring convolution kernels: worth 0.4 ms/step in round 1, but since the
+# weight-gradient kernels have their own stream it LOSES 0.6-1.2 ms (three interleaved same-box pairs:
+# 52.3 / 52.6 / 52.1 on vs 51.7 / 51.3 / 51.7 off -- the main chain then waits for the style kernels
+# behind the weight-gradient stream's work).  Off by default.
+_SIDE_STREAM = _os.environ.get("O2M_SIDE_STREAM", "0") == "1"
 _SIDE: dict = {}
 # O2M_DIRECT_STYLE_GRADS=1 (default): the style-gradient kernel adds the to_style gradients straight
 # into the parameters' .grad when those are the fp32 slices of a FusedAdam bucket (no autograd
@@ -328,8 +331,18 @@ _DIRECT_STYLE_GRADS = _os.environ.get("O2M_DIRECT_STYLE_GRADS", "1") == "1"
 _WGRAD_STREAM = _os.environ.get("O2M_WGRAD_STREAM", "1") == "1"
 # O2M_FUSED_IN_STATS=0: InstanceNorm statistics by their own pass over the conv output (A/B runs)
 _FUSED_IN_STATS = _os.environ.get("O2M_FUSED_IN_STATS", "1") == "1"
-# O2M_EARLY_FINALIZE=0 falls back to finalising every filter gradient in the end-of-backward callback
-_EARLY_FINALIZE = _os.environ.get("O2M_EARLY_FINALIZE", "1") == "1"
+# Early finalisation (a filter's gradient converted the moment its last use of the pass is reduced) exists for
+# the data-parallel reducer, which can then start a bucket segment's all-reduce inside backward; it makes the
+# main stream wait for the weight-gradient stream at every such point, which costs ~1 ms/step on one GPU
+# (same-box pairs: 50.4 / 50.8 with, 49.7 / 49.4 without).  Default: on exactly when a reducer has registered
+# its readiness hooks (GRAD_READY_HOOKS); O2M_EARLY_FINALIZE=0|1 forces it.
+_EARLY_FINALIZE = _os.environ.get("O2M_EARLY_FINALIZE")
+
+
+def _early_finalize() -> bool:
+    if _EARLY_FINALIZE is not None:
+        return _EARLY_FINALIZE == "1"
+    return bool(GRAD_READY_HOOKS)
 _WSTREAM: dict = {}
 
 
