@@ -158,7 +158,6 @@ class PreparedWeight:
         self.dw_acc = None
         self.gq_acc = None
         self.pending = False
-        self.uses = []  # deferred (x, gy, pad, pad_mode) of this backward pass
         self.dw2_acc = None  # space-to-depth form of dw_acc (s2d_wgrad), folded at finalize
         self.dw2_used = False
         # forward applications recorded for a backward that wants this filter's gradient, and how
@@ -227,7 +226,7 @@ class PreparedWeight:
         for t in (self.dw_acc, self.gq_acc, self.dw2_acc):
             if t is not None:
                 t.zero_()
-        self.uses, self.pending, self.dw2_used = [], False, False
+        self.pending, self.dw2_used = False, False
         self.fwd_uses = self.bwd_uses = 0
 
     S2D = 4  # output pixels per side folded into channels by the space-to-depth form
@@ -305,11 +304,6 @@ class PreparedWeight:
 
 import os as _os
 
-# O2M_DEFER_WGRAD=1 defers the weight-gradient reductions to the end of backward and runs ONE
-# multi-segment launch per layer (o2m_wgrad_desc.nseg).  Measured neutral on the 256x256 step
-# (72.1 / 72.6 ms deferred vs 72.3 / 72.4 ms immediate, same box) while keeping every x / gy
-# alive until the end of backward, so it is off by default.
-_DEFER_WGRAD = _os.environ.get("O2M_DEFER_WGRAD", "0") == "1"
 # The style-path kernels are B x C sized: alone on the GPU they leave 250 CUs idle for 6-14 us each
 # (~110 launches per generator backward).  O2M_SIDE_STREAM=1 runs them on a second HIP stream, ordered by
 # events, so they overlap the neighbouring convolution kernels: worth 0.4 ms/step in round 1, but since the
@@ -390,27 +384,11 @@ def _enter_backward_pass():
 GRAD_READY_HOOKS: dict = {}
 
 
-def _run_deferred_wgrads(prep):
-    """One multi-segment wgrad launch per group of same-shaped uses of the layer: a decoder
-    filter is applied to five batches per generator step, and reducing them together pays the
-    fp32-atomic slab once instead of five times."""
-    uses, prep.uses = prep.uses, []
-    groups = {}
-    for x, gy, pad, pad_mode in uses:
-        groups.setdefault((tuple(x.shape), tuple(gy.shape), pad, pad_mode), []).append((x, gy))
-    for (_, _, pad, pad_mode), pairs in groups.items():
-        for i in range(0, len(pairs), 8):
-            chunk = pairs[i: i + 8]
-            H.conv2d_wgrad(chunk[0][0], chunk[0][1], prep.dw_acc, pad=pad, pad_mode=pad_mode, more=chunk[1:])
-
-
 def _finalize_layer(prep):
     """Kernel-layout accumulators of one layer -> ``weight.grad`` (+= like autograd), clears them,
     and tells the data-parallel reducer that this filter's gradient is complete."""
     prep.pending = False
     prep.fwd_uses = prep.bwd_uses = 0
-    if prep.uses:
-        _run_deferred_wgrads(prep)
     if prep.dw2_used:
         prep.fold_s2d()
     w = prep.weight
@@ -689,8 +667,6 @@ class _ConvFn(torch.autograd.Function):
             with (torch.cuda.stream(wst) if wst is not None else contextlib.nullcontext()):
                 if s is None and residual is None and prep.s2d_ok(pad, pad_mode, Hh, Ww):
                     prep.s2d_wgrad(x, gu, pad, pad_mode)
-                elif _DEFER_WGRAD and x_eff is not None and gu.shape[2] % 32 == 0:
-                    prep.uses.append((x_eff, gu, pad, pad_mode))  # reduced at the end of backward
                 elif x_eff is not None:
                     H.conv2d_wgrad(x_eff, gu, dw_acc, pad=pad, pad_mode=pad_mode)
                 else:
