@@ -61,6 +61,21 @@ __device__ __forceinline__ void store8(unsigned short* p, const float (&v)[8]) {
   for (int i = 0; i < 4; ++i) r[i] = pack_bf2(v[2 * i], v[2 * i + 1]);
   *reinterpret_cast<u32x4*>(p) = r;
 }
+// Streaming form (non-temporal stores): for output rows far larger than the caches, which would otherwise evict
+// the input lines the filter taps re-read through L2.
+__device__ __forceinline__ void store8_stream(unsigned short* p, const float (&v)[8]) {
+  u32x4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[i] = pack_bf2(v[2 * i], v[2 * i + 1]);
+  __builtin_nontemporal_store(r, reinterpret_cast<u32x4*>(p));
+}
+__device__ __forceinline__ void store8_stream(float* p, const float (&v)[8]) {
+  f32x4 a, b;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { a[i] = v[i]; b[i] = v[4 + i]; }
+  __builtin_nontemporal_store(a, reinterpret_cast<f32x4*>(p));
+  __builtin_nontemporal_store(b, reinterpret_cast<f32x4*>(p + 4));
+}
 __device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
   f32x4 a, b;
 #pragma unroll

@@ -537,6 +537,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
   constexpr int LDS_TOTAL = lds_bytes<T, BM, BN, WAVES_M, WAVES_N>();
   constexpr int WPP_MAX = (LDS_TOTAL / (CSTR * 4) / WM) >= WAVES_M ? WAVES_M
                           : ((LDS_TOTAL / (CSTR * 4) / WM) >= 2 && WAVES_M % 2 == 0 ? 2 : 1);
+  // Outputs of >= 64 MiB leave through non-temporal stores: written normally, the 134-268 MB of rows of the
+  // 256 x 256 layers evict the input lines the filter taps re-read through L2 (kernel alone: 241 -> 210 us on
+  // 128 -> 64 at 256 x 256; whole step -0.4 ms in interleaved A/B runs; smaller outputs are better left in
+  // the caches for their consumer).
+  const bool stream_out = (size_t)M * Co * ES >= ((size_t)64 << 20);
   const int wpp = d.stats ? 1 : WPP_MAX;  // wave rows per pass
   const int npass = WAVES_M / wpp;
   const int wrow_ = wave / WAVES_N;
@@ -589,7 +594,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
 #pragma unroll
         for (int q = 0; q < 8; ++q) o[q] += rv[q];
       }
-      store8(Y + off, o);
+      if (stream_out) store8_stream(Y + off, o);
+      else store8(Y + off, o);
     }
     if (d.stats && mbase < M) {  // (a tile's trailing passes can lie past the problem: nothing to report)
       if constexpr (NT % VPR == 0 && VPR * 16 <= NT)
