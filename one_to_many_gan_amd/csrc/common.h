@@ -49,6 +49,20 @@ __device__ __forceinline__ void load8(const unsigned short* p, float (&v)[8]) {
     v[2 * i + 1] = __builtin_bit_cast(float, r[i] & 0xffff0000u);
   }
 }
+__device__ __forceinline__ void load8_stream(const unsigned short* p, float (&v)[8]) {
+  u32x4 r = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[2 * i] = __builtin_bit_cast(float, r[i] << 16);
+    v[2 * i + 1] = __builtin_bit_cast(float, r[i] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ void load8_stream(const float* p, float (&v)[8]) {
+  f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+  f32x4 b = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + 4));
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
+}
 __device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
   f32x4 a = *reinterpret_cast<const f32x4*>(p);
   f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
@@ -88,6 +102,20 @@ __device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
 // compare-and-branch blocks PER ELEMENT (with the tanh expansion in the middle): measured 8 of the 11 us
 // the p8 igemm's epilogue took.  So: ReLU / LeakyReLU / identity are one select each, driven by two
 // uniform values, and tanh sits behind ONE uniform branch per call (act_fwd8: per 8 values).
+// Streaming variants chosen at run time (block-uniform flag): tensors of >= 64 MiB that a kernel touches once.
+// Read or written normally they only push the lines the concurrent MFMA kernels re-read out of L2.
+constexpr size_t kStreamBytes = (size_t)64 << 20;
+template <typename T>
+__device__ __forceinline__ void load8x(const T* p, float (&v)[8], bool stream) {
+  if (stream) load8_stream(p, v);
+  else load8(p, v);
+}
+template <typename T>
+__device__ __forceinline__ void store8x(T* p, const float (&v)[8], bool stream) {
+  if (stream) store8_stream(p, v);
+  else store8(p, v);
+}
+
 __device__ __forceinline__ float act_fwd_piecewise(float v, bool relu, float neg) {
   return v > 0.f ? v : (relu ? 0.f : v * neg);
 }

@@ -59,6 +59,7 @@ __global__ __launch_bounds__(NT) void act_bwd_reduce_kernel(const T* __restrict_
   const int b = blockIdx.y, ch = blockIdx.x;
   const int cv = threadIdx.x % gm.CV, pl = threadIdx.x / gm.CV;
   const int pe = min(P, (ch + 1) * gm.chunk);
+  const bool big = (size_t)gridDim.y * P * C * sizeof(T) >= kStreamBytes;  // touched once: stream (common.h)
   float acc[16], mul[8];
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -69,9 +70,9 @@ __global__ __launch_bounds__(NT) void act_bwd_reduce_kernel(const T* __restrict_
     for (int p = ch * gm.chunk + pl; p < pe; p += gm.PL) {
       const size_t o = ((size_t)b * P + p) * C + cv * 8;
       float gv[8], yv[8], rv[8], ov[8];
-      load8(g + o, gv);
-      if constexpr (HAS_Y) load8(y + o, yv);
-      if constexpr (HAS_RES) load8(res + o, rv);
+      load8x(g + o, gv, big);
+      if constexpr (HAS_Y) load8x(y + o, yv, big);
+      if constexpr (HAS_RES) load8x(res + o, rv, big);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         // no y: reduce-only call (identity activation), sums[.][1] stays 0
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(NT) void act_bwd_reduce_kernel(const T* __restrict_
         acc[i] += d;
         acc[8 + i] += d * u;
       }
-      if (gu) store8(gu + o, ov);
+      if (gu) store8x(gu + o, ov, big);
     }
   }
   lanes_reduce<16>(acc, cv, pl, gm.CV, gm.PL, sm);
@@ -124,6 +125,7 @@ __global__ __launch_bounds__(NT) void fold_scale_dot_kernel(const T* __restrict_
   const int cv = threadIdx.x % gm.CV, pl = threadIdx.x / gm.CV;
   const int P = H * W, Hp = H + 2 * pad, Wp = W + 2 * pad;
   const int pe = min(P, (ch + 1) * gm.chunk);
+  const bool big = (size_t)gridDim.y * P * C * sizeof(T) >= kStreamBytes;
   float acc[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = 0.f;
@@ -147,25 +149,25 @@ __global__ __launch_bounds__(NT) void fold_scale_dot_kernel(const T* __restrict_
       for (int a = 0; a < ny; ++a)
         for (int c = 0; c < nx; ++c) {
           float t[8];
-          load8(gpad + (((size_t)b * Hp + ys[a]) * Wp + xs[c]) * C + cv * 8, t);
+          load8x(gpad + (((size_t)b * Hp + ys[a]) * Wp + xs[c]) * C + cv * 8, t, big);
 #pragma unroll
           for (int i = 0; i < 8; ++i) f[i] += t[i];
         }
       const size_t o = ((size_t)b * P + p) * C + cv * 8;
       if (dots) {
         float xv[8];
-        load8(x + o, xv);
+        load8x(x + o, xv, big);
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[i] += f[i] * xv[i];
         if (xmod) {  // by-product for the weight gradient: the modulated input x * s
 #pragma unroll
           for (int i = 0; i < 8; ++i) xv[i] *= sc[i];
-          store8(xmod + o, xv);
+          store8x(xmod + o, xv, big);
         }
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) f[i] *= sc[i];
-      store8(gx + o, f);
+      store8x(gx + o, f, big);
     }
   }
   if (dots) {
