@@ -217,3 +217,13 @@ def test_bench_refuses_more_ranks_than_gpus():
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
     assert "refusing to report a 64-GPU number" in r.stderr and "{" not in r.stdout
+
+
+def test_launch_timer_switch_is_host_side_state():
+    """o2m_launch_timing / o2m_launch_timing_read (bench.py's roofline source): the switch returns the previous
+    state and an empty record list reads back as no kernels -- no GPU involved."""
+    from one_to_many_gan_amd import _hip
+
+    assert _hip.launch_timing(True) is False
+    assert _hip.launch_timing(False) is True
+    assert _hip.launch_timing_read() == {}

@@ -440,3 +440,36 @@ def test_channel_sums_deterministic_mode_is_bitwise_reproducible_and_matches_ato
     assert float((a[0][:, 0].double() - want0).abs().max()) <= 1e-5 * float(want0.abs().max())
     want_dots = (g.double() * x.double()).sum(dim=(1, 2))
     assert float((a[1].double() - want_dots).abs().max()) <= 1e-5 * float(want_dots.abs().max())
+
+
+@pytest.mark.gpu
+def test_launch_timer_files_every_kernel_of_a_call_under_its_own_name():
+    """bench.py's roofline object times KERNELS, not calls: the data gradient of a reflect-padded 64x64 layer
+    (66x66 outputs = 273 tiles) runs as the phase-pipelined kernel over 256 tiles plus a 128x128 launch over
+    the tail rows, and the two must be filed separately with the algorithmic FLOP of the rows each covers."""
+    from one_to_many_gan_amd import _hip as H
+
+    B, S, C = 16, 66, 256
+    x = torch.randn(B, S, S, C, device="cuda").to(torch.bfloat16)
+    w = (torch.randn(C, 3, 3, C, device="cuda") / 48).to(torch.bfloat16)
+    y = torch.empty(B, S, S, C, device="cuda", dtype=torch.bfloat16)
+    g = torch.randn(B, S, S, C, device="cuda").to(torch.bfloat16)
+    dw = torch.zeros(C, 3, 3, C, device="cuda")
+    H.conv2d_fwd(x, w, y, pad=1, pad_mode=H.PAD_ZERO, act=H.ACT_NONE)  # untimed
+    assert H.launch_timing(True) is False
+    try:
+        H.conv2d_fwd(x, w, y, pad=1, pad_mode=H.PAD_ZERO, act=H.ACT_NONE)
+        H.conv2d_wgrad(x, g, dw, pad=1, pad_mode=H.PAD_ZERO)
+        stats = H.launch_timing_read()
+    finally:
+        H.launch_timing(False)
+    rows = B * S * S
+    per_row = 2.0 * C * 9 * C
+    p8 = stats["conv_igemm_p8<bf16,256x256>"]
+    tail = stats["conv_igemm<bf16,128x128,in_scale=0>"]
+    assert p8[0] == 1 and tail[0] == 1
+    assert p8[2] == 256 * 256 * per_row and tail[2] == (rows - 256 * 256) * per_row
+    assert 0 < tail[1] < p8[1] < 1e-3
+    wg = [k for k in stats if k.startswith("conv_wgrad<bf16")]
+    assert len(wg) == 1 and stats[wg[0]][2] == rows * per_row and stats["wgrad_reduce"][0] == 1
+    assert H.launch_timing_read() == {}  # reading clears the records
