@@ -199,15 +199,33 @@ def conv2d_fwd(x, w, y, *, in_scale=None, out_scale=None, bias=None, residual=No
 
 
 AMAX_PARTIALS = 1024
-_AMAX_WS: dict = {}
+
+
+class _StreamScratch:
+    """fp32 scratch buffers keyed by (device, stream).  The weight gradient runs on its own HIP stream beside the
+    main one, so a workspace shared by "whatever stream is current" would have two writers, and a regrow would
+    hand the old block back to the allocator while a kernel on the OTHER stream still used it (the round-2
+    multi-segment fault).  Each stream owns its buffer: every use and every regrow is ordered on that stream,
+    and the caching allocator reuses a freed block only behind the work of the stream it was allocated on."""
+
+    def __init__(self, floor: int):
+        self.floor, self.buf = floor, {}
+
+    def get(self, device, need: int) -> torch.Tensor:
+        key = (device, torch.cuda.current_stream(device).cuda_stream)
+        ws = self.buf.get(key)
+        if ws is None or ws.numel() < need:
+            ws = self.buf[key] = torch.empty(max(int(need), self.floor), dtype=torch.float32, device=device)
+        return ws
+
+
+_AMAX_WS = _StreamScratch(AMAX_PARTIALS)
 
 
 def quantize_fp8(x, y, deq):
     """Per-tensor fp8 quantisation of ``x`` (bf16 / fp32) into ``y`` (float8_e4m3fn or float8_e5m2, same shape):
     amax pass + scale-and-convert pass; ``deq`` (2 floats) receives {1 / scale, amax}."""
-    ws = _AMAX_WS.get(x.device)
-    if ws is None:
-        ws = _AMAX_WS[x.device] = torch.empty(AMAX_PARTIALS, dtype=torch.float32, device=x.device)
+    ws = _AMAX_WS.get(x.device, AMAX_PARTIALS)
     ops().amax(x, ws)
     ops().quantize_fp8(x, ws, y, deq)
 
@@ -217,7 +235,7 @@ def conv2d_stats_rows(x, w, y, *, pad, stride=1):
     return ops().conv2d_stats_rows(x, w, y, pad, stride)
 
 
-_SLABS: dict = {}  # device -> fp32 workspace of the slice partials (grown on demand, reused by every launch)
+_SLABS = _StreamScratch(16 << 20)  # (device, stream) -> fp32 workspace of the slice partials (grown on demand)
 WGRAD_ATOMICS = os.environ.get("O2M_WGRAD_ATOMICS", "0") == "1"  # A/B: float atomics instead of slab + reduce
 
 
@@ -225,10 +243,7 @@ def _slab_workspace(x, gy, dw, pad, pad_mode, splits, n_more, stride):
     if WGRAD_ATOMICS and not DETERMINISTIC:
         return None
     need = ops().conv2d_wgrad_slab_floats(x, gy, dw, pad, pad_mode, splits, n_more, stride)
-    ws = _SLABS.get(x.device)
-    if ws is None or ws.numel() < need:
-        ws = _SLABS[x.device] = torch.empty(max(need, 16 << 20), dtype=torch.float32, device=x.device)
-    return ws
+    return _SLABS.get(x.device, need)
 
 
 def conv2d_wgrad(x, gy, dw, *, in_scale=None, gy_scale=None, pad, pad_mode, splits=0, more=(), stride=1):
@@ -241,7 +256,7 @@ def conv2d_wgrad(x, gy, dw, *, in_scale=None, gy_scale=None, pad, pad_mode, spli
 
 
 DETERMINISTIC = False  # ops.set_deterministic(): ordered two-stage sums instead of fp32 atomics
-_PARTIALS: dict = {}   # device -> fp32 workspace of the per-chunk rows
+_PARTIALS = _StreamScratch(1 << 20)  # (device, stream) -> fp32 workspace of the per-chunk rows
 
 
 def _chan_partials(g, P, nv):
@@ -249,10 +264,7 @@ def _chan_partials(g, P, nv):
     if not DETERMINISTIC:
         return None
     need = ops().chan_partials_floats(g.shape[0], P, g.shape[-1], nv)
-    ws = _PARTIALS.get(g.device)
-    if ws is None or ws.numel() < need:
-        ws = _PARTIALS[g.device] = torch.empty(max(need, 1 << 20), dtype=torch.float32, device=g.device)
-    return ws
+    return _PARTIALS.get(g.device, need)
 
 
 def act_bwd_reduce(g, y, residual, out_mul, gu, sums, act):

@@ -13,6 +13,7 @@
 from __future__ import annotations
 
 import contextlib
+import os
 import random
 from collections.abc import Iterator
 
@@ -20,7 +21,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import ops
-from ..model.loss import kl_loss_func, path_loss_func, style_cycle_loss_func
+from ..model.loss import kl_loss_func, path_loss_func, path_loss_halves, style_cycle_loss_func
 
 
 class ImageBuffer:
@@ -115,6 +116,70 @@ def discriminator_step(config, device, discriminator, generator, mapping_network
     return out[0], (out[1], out[2])
 
 
+
+_BATCH_DECODES = os.environ.get("O2M_BATCH_DECODES", "1") == "1"
+
+
+def _separate_decodes(config, device, generator, discriminator, mapping_network, style_extractor, ada, latents,
+                      shoeprints, shoemarks):
+    """The reference's call sequence (training.py:171-234), one decoder pass per term."""
+    batch, lam, blocks = config["training"]["batch_size"], config["optimisation"], generator.n_style_blocks
+    z_print, z_mark = latents.chunk(2, dim=0)
+    w_zero = mapping_network.get_single_w(batch, blocks, device, 0)
+    rec = _l1(generator.decode(z_print, w_zero), shoeprints)
+    w_mark = style_extractor(shoemarks)
+    idt = _l1(generator.decode(z_mark, w_mark.expand(blocks, *w_mark.shape)), shoemarks)
+    w_trans = mapping_network.get_single_w(batch, blocks, device, 1)
+    generated = generator.decode(z_print, w_trans)
+    with _frozen(discriminator):
+        gan = _mse_to(discriminator(ada(generated)), 1.0)
+    style = style_cycle_loss_func(w_trans[-1], style_extractor(generated))
+    theta = torch.rand(batch).to(device)
+    lo, hi = lam["path_loss_jacobian_granularity"]
+    h = torch.ones_like(theta).uniform_(lo, hi)
+    d1, d2 = (theta + h / 2).clamp(0, 1), (theta - h / 2).clamp(0, 1)
+    w1, w2 = mapping_network.get_two_w(batch, blocks, device, (d1, d2))
+    path = path_loss_func(generator.extract(z_print, w1), generator.extract(z_print, w2), h)
+    return rec, idt, gan, style, path
+
+
+def _batched_decodes(config, device, generator, discriminator, mapping_network, style_extractor, ada, t_lat,
+                     shoeprints, shoemarks):
+    """The same five decoder passes as TWO: the three decodes (training.py:171-199) as one 3B batch and the two
+    feature extractions (training.py:226-231) as one 2B batch.  The decoder is per-sample throughout (style
+    modulation / demodulation per sample, no normalisation), so every sample's result is that of its separate
+    call -- with 2 instead of 5 launches per layer and each filter's weight gradient reduced once per group.
+    ``t_lat``: internal [2B, h, w, C] latents, chunk 0 = shoeprints, chunk 1 = shoemarks."""
+    batch, lam, blocks = config["training"]["batch_size"], config["optimisation"], generator.n_style_blocks
+    # Every style vector first, in the reference's draw order (builder.py:115-128, training.py:214-223:
+    # get_single_w(1) -> theta -> h -> get_two_w; get_single_w(0) and the style extractor draw nothing) ...
+    w_zero = mapping_network.get_single_w(batch, blocks, device, 0)
+    w_mark = style_extractor(shoemarks)
+    w_trans = mapping_network.get_single_w(batch, blocks, device, 1)
+    theta = torch.rand(batch).to(device)
+    lo, hi = lam["path_loss_jacobian_granularity"]
+    h = torch.ones_like(theta).uniform_(lo, hi)
+    d1, d2 = (theta + h / 2).clamp(0, 1), (theta - h / 2).clamp(0, 1)
+    w1, w2 = mapping_network.get_two_w(batch, blocks, device, (d1, d2))
+
+    w_dec = torch.cat([w_zero, w_mark.expand(blocks, *w_mark.shape), w_trans], dim=1)
+    images = generator._decode(ops.batch_gather(t_lat, batch, (0, 1, 0)), w_dec, collect=False, internal=True)
+    rec_t, idt_t, gen_t = ops.split_batch(images, 3)
+    n_img = shoeprints.numel()
+    rec = ops.l1_sum(rec_t, ops.to_internal(shoeprints)) / n_img
+    idt = ops.l1_sum(idt_t, ops.to_internal(shoemarks)) / n_img
+    generated = ops.to_public(gen_t, shoeprints.shape[1])
+    with _frozen(discriminator):
+        gan = _mse_to(discriminator(ada(generated)), 1.0)
+
+    style = style_cycle_loss_func(w_trans[-1], style_extractor(generated))
+
+    feats = generator._decode(ops.batch_gather(t_lat, batch, (0, 0)), torch.cat([w1, w2], dim=1),
+                              collect=True, internal=True)
+    path = path_loss_halves(feats, h)
+    return rec, idt, gan, style, path
+
+
 def generator_step(config, device, generator, discriminator, mapping_network, style_extractor,
                    generator_optimiser, mapping_network_optimiser, style_extractor_optimiser,
                    shoeprint_iter: Iterator[torch.Tensor], shoemark_iter: Iterator[torch.Tensor], ada,
@@ -135,27 +200,14 @@ def generator_step(config, device, generator, discriminator, mapping_network, st
     kl = kl_loss_func(latents, moment_hook=kl_moment_hook)
     if config["architecture"]["add_latent_noise"]:
         latents = latents + torch.randn_like(latents)
-    z_print, z_mark = latents.chunk(2, dim=0)
+    t_lat = ops.to_internal(latents)  # [2B, h, w, C]: chunk 0 = shoeprint latents, chunk 1 = shoemark latents
 
-    w_zero = mapping_network.get_single_w(batch, blocks, device, 0)
-    rec = _l1(generator.decode(z_print, w_zero), shoeprints)
-
-    w_mark = style_extractor(shoemarks)
-    idt = _l1(generator.decode(z_mark, w_mark.expand(blocks, *w_mark.shape)), shoemarks)
-
-    w_trans = mapping_network.get_single_w(batch, blocks, device, 1)
-    generated = generator.decode(z_print, w_trans)
-    with _frozen(discriminator):
-        gan = _mse_to(discriminator(ada(generated)), 1.0)
-
-    style = style_cycle_loss_func(w_trans[-1], style_extractor(generated))
-
-    theta = torch.rand(batch).to(device)
-    lo, hi = lam["path_loss_jacobian_granularity"]
-    h = torch.ones_like(theta).uniform_(lo, hi)
-    d1, d2 = (theta + h / 2).clamp(0, 1), (theta - h / 2).clamp(0, 1)
-    w1, w2 = mapping_network.get_two_w(batch, blocks, device, (d1, d2))
-    path = path_loss_func(generator.extract(z_print, w1), generator.extract(z_print, w2), h)
+    if not _BATCH_DECODES:  # O2M_BATCH_DECODES=0: the five decoder passes one by one (A/B of the batched form)
+        rec, idt, gan, style, path = _separate_decodes(config, device, generator, discriminator, mapping_network,
+                                                       style_extractor, ada, latents, shoeprints, shoemarks)
+    else:
+        rec, idt, gan, style, path = _batched_decodes(config, device, generator, discriminator, mapping_network,
+                                                      style_extractor, ada, t_lat, shoeprints, shoemarks)
 
     total = (gan + lam["identity_loss_lambda"] * idt + lam["reconstruction_loss_lambda"] * rec
              + lam["kl_loss_lambda"] * kl + lam["path_loss_lambda"] * path

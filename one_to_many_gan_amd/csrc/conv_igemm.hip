@@ -682,7 +682,7 @@ __device__ unsigned long long o2m_p8_estamps[2][12];  // epilogue timeline (abso
 // FMT: element format of the MFMA operands.  0 = bf16 (x, w, y bf16: v_mfma_f32_16x16x32_bf16).
 // 1 / 2 = BASELINE config #5, the fp8 path: x is OCP e4m3 (1) or e5m2 (2, gradients), w is e4m3, y / residual are
 // bf16, products on v_mfma_f32_16x16x32_{fp8,bf8}_fp8 with fp32 accumulation and one dequantisation factor
-// (d.deq_scale[0] * d.deq_scale[1], per-tensor scales of x and w) applied to the accumulator.  A 128-B LDS row then
+// (d.deq_scale[0] * d.deq_scale[2]: the {1/scale, amax} pairs of x and w sit at [0..1] and [2..3]) applied to the accumulator.  A 128-B LDS row then
 // holds 128 reduction elements: the same fills and LDS traffic feed twice the MFMA work of the bf16 form.
 template <int FMT>
 __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_desc d, const int m_begin, const int m_end) {

@@ -52,7 +52,8 @@ class BucketReducer:
                 self.seg_range.append((start, end, i + 1 - first))
                 start, first = end, i + 1
         self.n_seg = len(self.seg_range)
-        self.launch_log = []  # (segment, "hook" | "wait") of the current step, for the tests
+        self.launch_log = []  # (segment, "hook" | "wait") of the CURRENT step (cleared by _reset), for the tests
+        self.last_launch_log = []  # the finished step's log
         self._reset()
         optimiser.grad_scale = 1.0 / self.world
         optimiser.pre_step_hooks.append(self.wait)
@@ -68,6 +69,8 @@ class BucketReducer:
                 p.register_post_accumulate_grad_hook(self._on_grad)
 
     def _reset(self):
+        # the log is per step: a 150k-step run would otherwise keep ~10 tuples per step per rank forever
+        self.last_launch_log, self.launch_log = self.launch_log, []
         self.left = [n for _, _, n in self.seg_range]
         self.next = self.n_seg - 1  # segments go out last -> first
         self.seen = set()

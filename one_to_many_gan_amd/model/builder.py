@@ -111,7 +111,9 @@ class Generator(nn.Module):
                 t = m.run(t)
         return t
 
-    def _decode(self, t, w, collect: bool):
+    def _decode(self, t, w, collect: bool, internal: bool = False):
+        """``internal``: hand back NHWC buffers instead of public views (core/training.py runs several
+        decodes as one batch and splits the result itself)."""
         feats, i = [], 0
         # one UnbindBackward (a single stack) instead of a zeros + copy + accumulate trio per style block
         w = w.unbind(0)
@@ -129,12 +131,14 @@ class Generator(nn.Module):
             elif isinstance(m, EqualisedConv2d):
                 if collect:
                     break
-                return ops.to_public(m.run(t, reflect=3, act=H.ACT_TANH), self.input_nc)
+                y = m.run(t, reflect=3, act=H.ACT_TANH)
+                return y if internal else ops.to_public(y, self.input_nc)
             else:
                 continue
             i += 1
             if collect:
-                feats.append(ops.to_public(t, m.out_features if isinstance(m, Conv2dWeightModulate) else m.dim))
+                c = m.out_features if isinstance(m, Conv2dWeightModulate) else m.dim
+                feats.append((t, c) if internal else ops.to_public(t, c))
                 if i == self.n_style_blocks:
                     return feats
         raise ValueError("No return layers specified.")

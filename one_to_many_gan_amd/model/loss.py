@@ -78,3 +78,16 @@ def path_loss_func(features1: list[torch.Tensor], features2: list[torch.Tensor],
     for f1, f2 in zip(features1, features2):
         total = total + ops.sq_sum(ops.to_internal(f1), ops.to_internal(f2), inv_h2) / f1.numel()
     return total / len(features1)
+
+
+def path_loss_halves(features, cent_fin_diff_h: torch.Tensor) -> torch.Tensor:
+    """``path_loss_func`` for the fused step: ``features`` = [(internal NHWC buffer [2B, H, W, Cp], logical
+    channel count)] of ONE 2B extraction pass whose first half used the style w(theta + h/2) and second half
+    w(theta - h/2) (core/training.py).  Same value as path_loss_func(first halves, second halves, h) (reference
+    loss.py:98-111); padded channels are zero in both halves and do not count in the mean."""
+    inv_h2 = (1.0 / (cent_fin_diff_h.float() ** 2)).contiguous()
+    total = torch.zeros((), device=features[0][0].device)
+    for t, c in features:
+        b2, hh, ww, _ = t.shape
+        total = total + ops.halves_sq_sum(t, inv_h2) / (b2 // 2 * c * hh * ww)
+    return total / len(features)

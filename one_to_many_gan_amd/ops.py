@@ -763,6 +763,66 @@ def instance_norm_act(x, act=H.ACT_NONE, residual=None, eps=1e-5, stats=None):
     return y
 
 
+# ------------------------------------------------------------------- batch plumbing of the fused step
+#
+# generator_step runs its three decodes as ONE 3B pass and its two feature extractions as ONE 2B pass (every
+# op of the decoder is per-sample: core/training.py).  These three functions do the batch bookkeeping on
+# internal buffers without autograd's generic slice / cat machinery (which materialises a full-size zero
+# tensor per slice in backward).
+
+
+class _BatchGatherFn(torch.autograd.Function):
+    """out = cat([t[c*n:(c+1)*n] for c in chunks]) along the batch; backward sums the chunks back."""
+
+    @staticmethod
+    def forward(ctx, t, n, chunks):
+        ctx.n, ctx.chunks, ctx.shape = n, tuple(chunks), t.shape
+        return torch.cat([t[c * n:(c + 1) * n] for c in chunks], 0)
+
+    @staticmethod
+    def backward(ctx, g):
+        n, gt, seen = ctx.n, None, set()
+        g = g.contiguous()
+        gt = torch.empty(ctx.shape, dtype=g.dtype, device=g.device)
+        for k, c in enumerate(ctx.chunks):
+            src, dst = g[k * n:(k + 1) * n], gt[c * n:(c + 1) * n]
+            if c in seen:
+                dst.add_(src)
+            else:
+                dst.copy_(src)
+                seen.add(c)
+        for c in range(ctx.shape[0] // n):
+            if c not in seen:
+                gt[c * n:(c + 1) * n].zero_()
+        return gt, None, None
+
+
+def batch_gather(t, n, chunks):
+    """Internal buffer [m*n, ...] -> [len(chunks)*n, ...] made of its n-sample chunks ``chunks`` (repeats allowed)."""
+    return _BatchGatherFn.apply(t, n, chunks)
+
+
+class _SplitBatchFn(torch.autograd.Function):
+    """k equal, contiguous batch slices of an internal buffer (views); backward is one cat."""
+
+    @staticmethod
+    def forward(ctx, t, k):
+        ctx.k, ctx.shape = k, t.shape
+        return tuple(t.chunk(k, 0))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        ref = next(g for g in gs if g is not None)
+        n = ctx.shape[0] // ctx.k
+        parts = [g if g is not None else torch.zeros((n, *ctx.shape[1:]), dtype=ref.dtype, device=ref.device)
+                 for g in gs]
+        return torch.cat(parts, 0), None
+
+
+def split_batch(t, k):
+    return _SplitBatchFn.apply(t, k)
+
+
 # -------------------------------------------------------------------------------- resample
 
 
@@ -850,6 +910,34 @@ class _MomentsFn(torch.autograd.Function):
         ga = torch.empty_like(a)
         H.reduce_bwd(a, None, None, coef, ga, H.RED_MOM)
         return ga
+
+
+class _HalvesSqFn(torch.autograd.Function):
+    """sum_b w[b] * sum (t[b] - t[b + n])^2 over the two halves of a 2n batch (path_loss_func on the two
+    extraction passes that generator_step runs as one batch); returns an fp32 scalar."""
+
+    @staticmethod
+    def forward(ctx, t, w):
+        n = t.shape[0] // 2
+        a, b = t[:n], t[n:]
+        part = _partials(a.numel(), 1, t.device)
+        H.reduce_fwd(a, b, w, part, H.RED_SQ)
+        ctx.save_for_backward(t, w)
+        return part.sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        t, w = ctx.saved_tensors
+        n = t.shape[0] // 2
+        coef = (g.float() * 2.0).reshape(1).contiguous()
+        gt = torch.empty_like(t)
+        H.reduce_bwd(t[:n], t[n:], w, coef, gt[:n], H.RED_SQ)
+        torch.neg(gt[:n], out=gt[n:])
+        return gt, None
+
+
+def halves_sq_sum(t, w):
+    return _HalvesSqFn.apply(t, w)
 
 
 def l1_sum(a, b):

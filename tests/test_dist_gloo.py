@@ -128,8 +128,9 @@ def _worker(rank, world, port, q):
                 (p.grad if p.grad is not None else torch.zeros_like(p)).flatten() for p in ref_net.parameters()])
             for hook in opt.pre_step_hooks:
                 hook()
-            assert [why for _, why in reducer.launch_log] == (["wait"] if step == 0 else [])
-            reducer.launch_log.clear()
+            # wait() closes the step: the log moves to last_launch_log and the live one starts empty
+            assert [why for _, why in reducer.last_launch_log] == (["wait"] if step == 0 else [])
+            assert reducer.launch_log == []
             # gather every rank's local gradient and compare with the reduced bucket
             allg = [torch.empty_like(mine) for _ in range(world)]
             dist.all_gather(allg, mine)

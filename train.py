@@ -120,6 +120,8 @@ def run(config, device, steps, shoeprint_iter, shoemark_iter, resume=None, log=p
                         ("path", path), ("style", style)):
             getattr(logger, f"log_{name}_losses").append(v)
         if rank != 0:
+            if (step + 1) % ev["log_interval"] == 0:
+                logger.initialise_trackers()  # only rank 0 prints (and thereby resets) the windows
             continue
         if (step + 1) % ev["log_interval"] == 0 or step + 1 == steps:
             line = logger.print(step + 1)  # the reference's line, also appended to <run>/log (train.py:253-267)
