@@ -104,7 +104,7 @@ typedef struct {
   int32_t stride;         /* 0 or 1: stride 1; s > 1: Ho = (H + 2*pad - KH)/s + 1.  Used by the host
                              for the space-to-depth form of the N = 3 image conv (a 7x7 stride-1
                              conv with 3 outputs = a 10x10 stride-4 conv with 48 outputs) */
-  int32_t reserved[1];
+  int32_t stats_mode;     /* what `stats` receives: O2M_STATS_MOMENTS (0) or O2M_STATS_DOT (1), below */
   float* stats;           /* NULL, or InstanceNorm partial sums emitted by the epilogue:
                              stats[(m / R) * Co * 2 + o * 2 + {0, 1}] = sum / sum of squares of y[., o] (fp32,
                              before the rounding to `dtype`) over the R consecutive output pixels m .. m+R-1,
@@ -117,12 +117,26 @@ typedef struct {
                              {1 / scale, amax} that o2m_quantize_fp8 wrote for x ([0], [1]) and for w ([2], [3]);
                              the accumulator is multiplied by [0] * [2] before out_scale / bias / activation.
                              Scales stay on the device: no host sync between quantisation and the convolution. */
+  const void* aux;        /* stats_mode O2M_STATS_DOT: tensor of y's shape and dtype.  The epilogue then emits
+                             stats[(m / R) * Co * 2 + o * 2] = sum over the R pixels of acc[., o] * aux[., o], acc =
+                             the convolution result BEFORE out_scale (0 in the odd slots), i.e. the data gradient of
+                             a zero-padded modulated conv leaves the kernel already multiplied by the style
+                             (out_scale = s) with its style dot sum_p g * x (aux = the layer's input x) as row-block
+                             partials: the separate o2m_fold_scale_dot pass over the gradient and x (layers.py:152-154
+                             backward) is not run.  Requires R > 0, act NONE, no bias, no residual.
+                             o2m_conv2d_dots_finalize adds a sample's partials in block order. */
 } o2m_conv_desc;
+#define O2M_STATS_MOMENTS 0
+#define O2M_STATS_DOT 1
 int o2m_conv2d_fwd(const o2m_conv_desc* d, void* stream);
 /* Rows per InstanceNorm partial for this problem (the tile configuration o2m_conv2d_fwd would select),
  * or 0 when the epilogue cannot emit them (Ho*Wo not a multiple of the tile's row block: the odd-sized
  * discriminator maps -- the caller then runs o2m_instnorm_stats).  d->stats itself is not read. */
 int32_t o2m_conv2d_stats_rows(const o2m_conv_desc* d);
+/* dots[b][c] = sum over the nchunks = Ho*Wo / R row blocks of sample b of the O2M_STATS_DOT partials
+ * (partial [B][nchunks][C][2], even slots), in block order: fixed summation order, no atomics. */
+int o2m_conv2d_dots_finalize(const float* partial, float* dots, int32_t B, int32_t C, int32_t nchunks,
+                             void* stream);
 
 /* Per-tensor fp8 quantisation (config #5).  Two launches per tensor, no host round trip, no atomics:
  *   o2m_amax         : partial[k] = max |x| over block k's share, k < O2M_AMAX_PARTIALS (all written)
@@ -245,16 +259,24 @@ int o2m_act_bwd_reduce(const void* g, const void* y, const void* residual,
 
 /* Backward of ReflectionPad2d fused with the style scale and the style-gradient dot:
  *   gfold = fold_reflect(gpad)             (pad == 0: identity)
- *   gx[b,y,x,c]   = gfold[b,y,x,c] * scale[b,c]      (scale NULL: 1)
+ *   gx[b,y,x,c]   = gfold[b,y,x,c] * scale[b,c] + gres[b,y,x,c]   (scale NULL: 1; gres NULL: 0)
  *   dots[b,c]    += sum_{y,x} gfold[b,y,x,c] * x[b,y,x,c]   (dots/x NULL: skipped)
  *   xs[b,y,x,c]   = x[b,y,x,c] * scale[b,c]                  (xs NULL: skipped; needs dots)
- * gpad is [B][H+2p][W+2p][C]; gx, x, xs are [B][H][W][C]; dots fp32 [B][C] zeroed by caller.
+ * gpad is [B][H+2p][W+2p][C]; gx, x, xs, gres are [B][H][W][C]; dots fp32 [B][C] zeroed by caller.
  * xs is the modulated input, a by-product for o2m_conv2d_wgrad (x is being read anyway).
- * partials: NULL (fp32 atomics into dots) or o2m_chan_partials_floats(B, H*W, C, 1) floats of
- * workspace for the ordered two-stage sum, as in o2m_act_bwd_reduce.
+ * gres: the gradient that reaches the layer's input through a residual connection around it
+ * (blocks.py:33,68: x + block(x)) -- added here instead of by a separate elementwise pass.
+ * Fused activation backward (act_sums != NULL; the ModulatedResnetBlock's conv -> ReLU -> conv chain,
+ * blocks.py:49-57): x is ALSO the output y of the layer below, which applied `act` and the
+ * demodulation act_mul[b,c]; the stored tensor is then that layer's o2m_act_bwd_reduce result
+ *   gx <- gx * act'(x) * act_mul[b,c],  act_sums[b,0,c] += sum gx act'(x),  act_sums[b,1,c] += sum gx act'(x) x
+ * (act_sums fp32 [B][2][C], zeroed by the caller; act in {none, relu, lrelu}).
+ * partials: NULL (fp32 atomics) or o2m_chan_partials_floats(B, H*W, C, act_sums ? 3 : 1) floats of
+ * workspace for the ordered two-stage sums, as in o2m_act_bwd_reduce.
  */
 int o2m_fold_scale_dot(const void* gpad, const void* x, const float* scale, void* gx,
-                       float* dots, void* xs, int32_t B, int32_t H, int32_t W, int32_t C,
+                       float* dots, void* xs, const void* gres, int32_t act, const float* act_mul,
+                       float* act_sums, int32_t B, int32_t H, int32_t W, int32_t C,
                        int32_t pad, int32_t dtype, float* partials, void* stream);
 
 /* ------------------------------------------------------------------------------------

@@ -32,7 +32,8 @@ BF16, F32, FP8_E4M3, BF8_E5M2 = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 PAD_ZERO, PAD_REFLECT = 0, 1
 RED_L1, RED_SQ, RED_MOM = 0, 1, 2
-ABI_VERSION = 17
+STATS_MOMENTS, STATS_DOT = 0, 1
+ABI_VERSION = 18
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -42,8 +43,8 @@ class ConvDesc(C.Structure):
                 ("bias", _vp), ("residual", _vp),
                 ("B", _i32), ("H", _i32), ("W", _i32), ("Ci", _i32), ("Co", _i32), ("KH", _i32),
                 ("KW", _i32), ("pad", _i32), ("pad_mode", _i32), ("act", _i32), ("dtype", _i32),
-                ("w_batch_stride", _i32), ("stride", _i32), ("reserved", _i32 * 1), ("stats", _vp),
-                ("deq_scale", _vp)]
+                ("w_batch_stride", _i32), ("stride", _i32), ("stats_mode", _i32), ("stats", _vp),
+                ("deq_scale", _vp), ("aux", _vp)]
 
 
 class WgradDesc(C.Structure):
@@ -61,6 +62,7 @@ SIGNATURES = {
     "o2m_launch_timing_read": (_i32, [_vp, _i32]),
     "o2m_conv2d_fwd": (_i32, [C.POINTER(ConvDesc), _vp]),
     "o2m_conv2d_stats_rows": (_i32, [C.POINTER(ConvDesc)]),
+    "o2m_conv2d_dots_finalize": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "o2m_amax": (_i32, [_vp, _vp, _i64, _i32, _vp]),
     "o2m_quantize_fp8": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "o2m_instnorm_finalize": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),
@@ -74,7 +76,8 @@ SIGNATURES = {
     "o2m_prepare_weights": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, C.c_float,
                                    _i32, _vp]),
     "o2m_modulate_weights": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
-    "o2m_fold_scale_dot": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "o2m_fold_scale_dot": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32,
+                                  _vp, _vp]),
     "o2m_instnorm_ws_floats": (C.c_size_t, [_i32, _i32, _i32]),
     "o2m_instnorm_stats": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp]),
     "o2m_instnorm_apply": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
@@ -190,12 +193,17 @@ def check(err: int, what: str):
 
 
 def conv2d_fwd(x, w, y, *, in_scale=None, out_scale=None, bias=None, residual=None, pad, pad_mode, act,
-               per_sample_w=False, stride=1, stats=None, deq=None):
-    """``stats``: fp32 workspace for the InstanceNorm partial sums of y (see o2m_conv_desc.stats).
+               per_sample_w=False, stride=1, stats=None, deq=None, aux=None):
+    """``stats``: fp32 workspace for the InstanceNorm partial sums of y (see o2m_conv_desc.stats) -- or, with
+    ``aux`` (a tensor of y's shape), for the style-dot partials sum_p acc * aux (O2M_STATS_DOT).
     ``deq``: fp8 operands (x float8_e4m3fn / float8_e5m2, w float8_e4m3fn): device tensor of the two
     dequantisation factors."""
     return ops().conv2d_fwd(x, w, y, in_scale, out_scale, bias, residual, pad, pad_mode, act, per_sample_w, stride,
-                            stats, deq)
+                            stats, deq, aux)
+
+
+def conv2d_dots_finalize(partial, dots, nchunks):
+    ops().conv2d_dots_finalize(partial, dots, nchunks)
 
 
 AMAX_PARTIALS = 1024
@@ -294,9 +302,13 @@ def modulate_weights(w32, s, out):
     ops().modulate_weights(w32, s, out)
 
 
-def fold_scale_dot(gpad, x, scale, gx, dots, pad, xs=None):
-    partials = _chan_partials(gx, gx.shape[1] * gx.shape[2], 1) if dots is not None else None
-    ops().fold_scale_dot(gpad, x, scale, gx, dots, pad, xs, partials)
+def fold_scale_dot(gpad, x, scale, gx, dots, pad, xs=None, *, gres=None, act=ACT_NONE, act_mul=None, act_sums=None):
+    """``gres``: residual-path gradient added to gx.  ``act_sums`` (with ``act`` / ``act_mul``): fused backward of
+    the activation whose output is x (see o2m_fold_scale_dot)."""
+    nv = 3 if act_sums is not None else 1
+    partials = (_chan_partials(gx, gx.shape[1] * gx.shape[2], nv)
+                if (dots is not None or act_sums is not None) else None)
+    ops().fold_scale_dot(gpad, x, scale, gx, dots, pad, xs, gres, act, act_mul, act_sums, partials)
 
 
 def instnorm_ws_floats(B, P, Cn):

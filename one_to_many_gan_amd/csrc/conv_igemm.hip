@@ -542,6 +542,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
   // 128 -> 64 at 256 x 256; whole step -0.4 ms in interleaved A/B runs; smaller outputs are better left in
   // the caches for their consumer).
   const bool stream_out = (size_t)M * Co * ES >= ((size_t)64 << 20);
+  const bool dot_mode = d.stats && d.stats_mode == O2M_STATS_DOT;
+  const T* __restrict__ AUX = static_cast<const T*>(d.aux);
   const int wpp = d.stats ? 1 : WPP_MAX;  // wave rows per pass
   const int npass = WAVES_M / wpp;
   const int wrow_ = wave / WAVES_N;
@@ -571,6 +573,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
       const f32x4 a = *reinterpret_cast<const f32x4*>(csm + row * CSTR + ec8 * 8);
       const f32x4 b = *reinterpret_cast<const f32x4*>(csm + row * CSTR + ec8 * 8 + 4);
       float o[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+      const size_t off = (size_t)m * Co + en;
+      if (dot_mode) {  // style dot of the data gradient: sum over pixels of (unscaled result) * aux
+        float xv[8];
+        load8x(AUX + off, xv, stream_out);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) st[q] += o[q] * xv[q];
+      }
       if (d.out_scale && !b_uniform) {
         const float* sp = d.out_scale + (size_t)(m / HoWo) * Co + en;
         const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 4);
@@ -582,12 +591,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
       }
 #pragma unroll
       for (int q = 0; q < 8; ++q) o[q] += ebias[q];
-      if (d.stats) {
+      if (d.stats && !dot_mode) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) { st[q] += o[q]; st[8 + q] += o[q] * o[q]; }
       }
       act_fwd8(o, act);
-      const size_t off = (size_t)m * Co + en;
       if (R) {
         float rv[8];
         load8(R + off, rv);
@@ -955,6 +963,11 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
   constexpr int VPR = BN / 8;
   const int act = d.act;
   const float deq = (FMT != 0 && d.deq_scale) ? d.deq_scale[0] * d.deq_scale[2] : 1.f;  // {1/scale, amax} of x, of w
+  // outputs of >= 64 MiB leave through non-temporal stores, as in conv_igemm_kernel (no cache level holds them for
+  // the consumer; written normally they evict the input lines the taps re-read)
+  const bool stream_out = (size_t)M * Co * sizeof(T) >= ((size_t)64 << 20);
+  const bool dot_mode = d.stats && d.stats_mode == O2M_STATS_DOT;
+  const T* __restrict__ AUX = static_cast<const T*>(d.aux);
   static_assert(NT % VPR == 0, "one channel vector per thread");
   const int ec8 = tid % VPR, erow = tid / VPR, en = n0 + ec8 * 8;
   const bool ecol_ok = en < Co;
@@ -1005,6 +1018,13 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
       const f32x4 a = *reinterpret_cast<const f32x4*>(csm + row * CSTR + ec8 * 8);
       const f32x4 b = *reinterpret_cast<const f32x4*>(csm + row * CSTR + ec8 * 8 + 4);
       float o[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+      const size_t off = (size_t)m * Co + en;
+      if (dot_mode) {  // style dot of the data gradient: sum over pixels of (unscaled result) * aux
+        float xv[8];
+        load8x(AUX + off, xv, stream_out);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) st[q] += o[q] * deq * xv[q];
+      }
       if (d.out_scale && !b_uniform) {
         const float* sp = d.out_scale + (size_t)(m / HoWo) * Co + en;
         const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 4);
@@ -1016,19 +1036,18 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
       }
 #pragma unroll
       for (int q = 0; q < 8; ++q) o[q] += ebias[q];
-      if (d.stats) {
+      if (d.stats && !dot_mode) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) { st[q] += o[q]; st[8 + q] += o[q] * o[q]; }
       }
       act_fwd8(o, act);
-      const size_t off = (size_t)m * Co + en;
       if (R) {
         float rv[8];
         load8(R + off, rv);
 #pragma unroll
         for (int q = 0; q < 8; ++q) o[q] += rv[q];
       }
-            store8(Y + off, o);
+      store8x(Y + off, o, stream_out);
     }
     if (d.stats && mbase < M) stats_block_reduce<NT, VPR>(st, csm, d.stats, (long)(mbase / 128), n0, Co, tid);
     if (pass == 0) P8_ESTAMP(5); else P8_ESTAMP(9);
@@ -1148,6 +1167,29 @@ extern "C" int o2m_debug_stamps(unsigned long long* out) {
 }
 #endif
 
+namespace {
+// dots[b][c] = sum over the row blocks of a sample of the epilogue's O2M_STATS_DOT partials, in block order
+__global__ __launch_bounds__(256) void dots_finalize_kernel(const float* __restrict__ partial, float* __restrict__ dots,
+                                                            int BC, int C, int nchunks) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= BC) return;
+  const int b = idx / C, c = idx - b * C;
+  float s = 0.f;
+#pragma unroll 8
+  for (int ch = 0; ch < nchunks; ++ch) s += partial[(((size_t)b * nchunks + ch) * C + c) * 2];
+  dots[idx] = s;
+}
+}  // namespace
+
+extern "C" int o2m_conv2d_dots_finalize(const float* partial, float* dots, int32_t B, int32_t C, int32_t nchunks,
+                                        void* stream) {
+  if (!partial || !dots || B <= 0 || C <= 0 || nchunks <= 0) return O2M_ERR_BAD_ARG;
+  hipLaunchKernelGGL(dots_finalize_kernel, dim3((B * C + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     partial, dots, B * C, C, nchunks);
+  O2M_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int32_t o2m_conv2d_stats_rows(const o2m_conv_desc* d) {
   if (!d || d->B <= 0 || d->H <= 0 || d->W <= 0 || d->KH <= 0 || d->KW <= 0 || d->pad < 0) return 0;
   const bool f8 = d->dtype == O2M_FP8_E4M3 || d->dtype == O2M_BF8_E5M2;
@@ -1177,7 +1219,12 @@ extern "C" int o2m_conv2d_fwd(const o2m_conv_desc* d, void* stream) {
     const long howo = (long)(d->H + 2 * d->pad - d->KH + 1) * (d->W + 2 * d->pad - d->KW + 1);
     if (howo % 256 != 0 || d->in_scale) return O2M_ERR_BAD_ARG;
   }
-  if (d->stats && (d->act != O2M_ACT_NONE || d->residual || d->out_scale || o2m_conv2d_stats_rows(d) == 0))
+  if (d->stats_mode != O2M_STATS_MOMENTS && d->stats_mode != O2M_STATS_DOT) return O2M_ERR_BAD_ARG;
+  if (d->stats && d->stats_mode == O2M_STATS_MOMENTS &&
+      (d->act != O2M_ACT_NONE || d->residual || d->out_scale || o2m_conv2d_stats_rows(d) == 0))
+    return O2M_ERR_BAD_ARG;
+  if (d->stats && d->stats_mode == O2M_STATS_DOT &&
+      (!d->aux || d->act != O2M_ACT_NONE || d->residual || d->bias || o2m_conv2d_stats_rows(d) == 0))
     return O2M_ERR_BAD_ARG;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (f8) {

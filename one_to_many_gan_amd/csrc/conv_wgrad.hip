@@ -181,10 +181,19 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const o2m_wgrad_desc 
 
   // two register sets: stage i+2 is in flight while stage i+1 waits to be written to LDS
   Stg<T> sg[2][GLD], sx_[2][XLD];
-  int xsamp[2][XLD];  // sample index of each staged X row (only read when XS)
+  // XS: the style scale of each staged X row's sample, fetched WITH the row (two more 16-B loads per row in the
+  // same always-issued batch, so the loop's waits stay counted; fetched at LDS-write time they made every stage
+  // wait for the youngest load, i.e. drained the prefetch)
+  f32x4 xsc[2][XS ? XLD : 1][2];
 
   // Always issued, also past m_end (every lane then reads the out-of-range offset = zeros, no
   // memory traffic): the number of loads in flight stays static, so the waits stay counted.
+  const rsrc_t scr = make_rsrc(d.in_scale, XS ? (unsigned)((size_t)d.B * Ci * 4) : 0u);
+  auto load_scale = [&](const int slot, const int j, const int samp) {
+    const unsigned off = (kxv && samp < d.B) ? (unsigned)(samp * Ci + ci0) * 4u : OOB_OFF;  // past the end: zeros
+    xsc[slot][XS ? j : 0][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(scr, (int)off, 0, 0));
+    xsc[slot][XS ? j : 0][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(scr, (int)off + 16, 0, 0));
+  };
   auto load_stage = [&](const int slot, int ms) {
     const int seg = min(ms / Mseg, nseg - 1);  // uniform; stages never straddle segments
     if (seg != cur_seg) {
@@ -213,7 +222,7 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const o2m_wgrad_desc 
         if (reflect) ix = ix < 0 ? -ix : (ix >= W ? 2 * W - 2 - ix : ix);
         else ok = ok && (unsigned)ix < (unsigned)W;
         stg_load(sx_[slot][j], xr, ok ? (unsigned)((rowbase + ix) * Ci + ci0) * ES : OOB_OFF);
-        xsamp[slot][j] = sb;
+        if constexpr (XS) load_scale(slot, j, sb);
       }
       sx += BMR;
       if (sx >= Wo) { sx = 0; if (++sy >= Ho) { sy = 0; ++sb; } }
@@ -229,7 +238,7 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const o2m_wgrad_desc 
           ok = ok && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
         }
         stg_load(sx_[slot][j], xr, ok ? (unsigned)(((pb[j] * H + iy) * W + ix) * Ci + ci0) * ES : OOB_OFF);
-        xsamp[slot][j] = pb[j];
+        if constexpr (XS) load_scale(slot, j, pb[j]);
         px[j] += BMR;
         while (px[j] >= Wo) { px[j] -= Wo; ++py[j]; }
         while (py[j] >= Ho) { py[j] -= Ho; ++pb[j]; }
@@ -255,8 +264,11 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const o2m_wgrad_desc 
     }
 #pragma unroll
     for (int j = 0; j < XLD; ++j) {
-      const float* sc = nullptr;
-      if constexpr (XS) sc = d.in_scale + (size_t)min(xsamp[slot][j], d.B - 1) * Ci + (kxv ? ci0 : 0);
+      float sc[8] = {};
+      if constexpr (XS) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { sc[q] = xsc[slot][j][0][q]; sc[4 + q] = xsc[slot][j][1][q]; }
+      }
       put8<T, XS>(sx_[slot][j], sc, x_hi, x_lo, (xr0 + XRS * j) * XSTR + xc * 16);
     }
   };

@@ -113,25 +113,36 @@ __global__ __launch_bounds__(NT) void chunk_sum_kernel(float* __restrict__ out, 
   }
 }
 
-// ---- reflect-pad backward (fold) + style scale + style dot ----------------------------------
-template <typename T>
+// ---- reflect-pad backward (fold) + style scale + style dot (+ residual gradient, + next activation) --------
+// FUSE_ACT: the tensor this kernel would store is the gradient of an activation output y == x (the layer below
+// applied act and a demodulation d, and its output IS this layer's input x): instead of storing gx and having
+// o2m_act_bwd_reduce read it and x again, the kernel stores gu = gx * act'(x) * act_mul[b,c] and adds that layer's
+// sums {sum gx act'(x), sum gx act'(x) x} -- the ModulatedResnetBlock's conv2 -> ReLU -> conv1 backward chain in
+// one pass (4 tensor passes instead of 7).
+template <typename T, bool FUSE_ACT>
 __global__ __launch_bounds__(NT) void fold_scale_dot_kernel(const T* __restrict__ gpad, const T* __restrict__ x,
                                                             const float* __restrict__ scale,
                                                             T* __restrict__ gx, float* __restrict__ dots,
-                                                            T* __restrict__ xmod, float* __restrict__ partials,
-                                                            int H, int W, int C, int pad, ChanGeom gm) {
+                                                            T* __restrict__ xmod, const T* __restrict__ gres,
+                                                            const float* __restrict__ act_mul,
+                                                            float* __restrict__ act_sums, float* __restrict__ partials,
+                                                            int H, int W, int C, int pad, int act, ChanGeom gm) {
   extern __shared__ float sm[];
+  constexpr int NV = FUSE_ACT ? 24 : 8;  // accumulators per thread: dots (+ the two activation sums)
   const int b = blockIdx.y, ch = blockIdx.x;
   const int cv = threadIdx.x % gm.CV, pl = threadIdx.x / gm.CV;
   const int P = H * W, Hp = H + 2 * pad, Wp = W + 2 * pad;
   const int pe = min(P, (ch + 1) * gm.chunk);
   const bool big = (size_t)gridDim.y * P * C * sizeof(T) >= kStreamBytes;
-  float acc[8];
+  float acc[NV];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-  float sc[8];
+  for (int i = 0; i < NV; ++i) acc[i] = 0.f;
+  float sc[8], am[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) sc[i] = scale ? scale[(size_t)b * C + cv * 8 + i] : 1.f;
+  for (int i = 0; i < 8; ++i) {
+    sc[i] = scale ? scale[(size_t)b * C + cv * 8 + i] : 1.f;
+    am[i] = (FUSE_ACT && act_mul) ? act_mul[(size_t)b * C + cv * 8 + i] : 1.f;
+  }
   if (pl < gm.PL) {
 #pragma unroll 2
     for (int p = ch * gm.chunk + pl; p < pe; p += gm.PL) {
@@ -154,34 +165,71 @@ __global__ __launch_bounds__(NT) void fold_scale_dot_kernel(const T* __restrict_
           for (int i = 0; i < 8; ++i) f[i] += t[i];
         }
       const size_t o = ((size_t)b * P + p) * C + cv * 8;
+      float xv[8];
+      if (dots || FUSE_ACT) load8x(x + o, xv, big);
       if (dots) {
-        float xv[8];
-        load8x(x + o, xv, big);
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[i] += f[i] * xv[i];
         if (xmod) {  // by-product for the weight gradient: the modulated input x * s
+          float xm[8];
 #pragma unroll
-          for (int i = 0; i < 8; ++i) xv[i] *= sc[i];
-          store8x(xmod + o, xv, big);
+          for (int i = 0; i < 8; ++i) xm[i] = xv[i] * sc[i];
+          store8x(xmod + o, xm, big);
         }
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) f[i] *= sc[i];
+      if (gres) {  // gradient arriving through a residual connection around the layer (added, not scaled)
+        float rv[8];
+        load8x(gres + o, rv, big);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] += rv[i];
+      }
+      if constexpr (FUSE_ACT) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float dl = f[i] * act_bwd_from_out(xv[i], act);
+          acc[8 + i] += dl;
+          acc[16 + i] += dl * xv[i];
+          f[i] = dl * am[i];
+        }
+      }
       store8x(gx + o, f, big);
     }
   }
-  if (dots) {
-    lanes_reduce<8>(acc, cv, pl, gm.CV, gm.PL, sm);
+  if (dots || FUSE_ACT) {
+    lanes_reduce<NV>(acc, cv, pl, gm.CV, gm.PL, sm);
     __syncthreads();
-    if (pl == 0)
+    if (pl == 0) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) sm[cv * 8 + i] = acc[i];
-    __syncthreads();
-    if (partials) {
-      for (int t = threadIdx.x; t < C; t += NT) partials[((size_t)b * gridDim.x + ch) * C + t] = sm[t];
-    } else {
-      for (int t = threadIdx.x; t < C; t += NT) atomicAdd(dots + (size_t)b * C + t, sm[t]);
+      for (int i = 0; i < 8; ++i) {
+        sm[cv * 8 + i] = acc[i];
+        if constexpr (FUSE_ACT) { sm[C + cv * 8 + i] = acc[8 + i]; sm[2 * C + cv * 8 + i] = acc[16 + i]; }
+      }
     }
+    __syncthreads();
+    constexpr int ROWS = FUSE_ACT ? 3 : 1;  // [dots | sums0 | sums1]
+    if (partials) {
+      for (int t = threadIdx.x; t < ROWS * C; t += NT) partials[((size_t)b * gridDim.x + ch) * ROWS * C + t] = sm[t];
+    } else {
+      for (int t = threadIdx.x; t < ROWS * C; t += NT) {
+        if (t < C) { if (dots) atomicAdd(dots + (size_t)b * C + t, sm[t]); }
+        else atomicAdd(act_sums + (size_t)b * 2 * C + (t - C), sm[t]);
+      }
+    }
+  }
+}
+
+// deterministic mode of the fused form: partial rows [dots | sums0 | sums1] -> dots [B][C], sums [B][2][C]
+__global__ __launch_bounds__(NT) void chunk_sum3_kernel(float* __restrict__ dots, float* __restrict__ sums,
+                                                        const float* __restrict__ partials, int nchunks, int C) {
+  const int b = blockIdx.x;
+  for (int t = threadIdx.x; t < 3 * C; t += NT) {
+    float* dst = t < C ? (dots ? dots + (size_t)b * C + t : nullptr) : sums + (size_t)b * 2 * C + (t - C);
+    if (!dst) continue;
+    float a = *dst;
+    for (int c = 0; c < nchunks; ++c) a += partials[((size_t)b * nchunks + c) * 3 * C + t];
+    *dst = a;
   }
 }
 
@@ -449,6 +497,88 @@ __global__ __launch_bounds__(NT) void resample2x2_kernel(const T* __restrict__ x
   if (has_y1) {
     store8(o00 + (size_t)Wo * C, acc[1][0]);
     if (has_x1) store8(o00 + (size_t)Wo * C + C, acc[1][1]);
+  }
+}
+
+// Tile form for WIDE operators (the transposed 6-tap upsample: 36 taps per output).  One block owns an
+// OH x OW output tile of CVB channel vectors and runs the separable operator in two phases through LDS:
+//   A: thread (patch column, channel vector) loads the PH = SY (OH - 1) + TY input rows of its column ONCE
+//      (coalesced: a wave covers 4 consecutive pixels x 256 B) and forms the OH vertically combined rows
+//      -> LDS [OH][PW][2][CVB] float4 (two planes, so a lane group's 16-B reads are contiguous);
+//   B: thread (output pixel, channel vector) combines its TX horizontal taps from LDS and stores 16 B.
+// Every input element is fetched once (plus the tile halo, served by L2) and every output written once: the
+// two 1-D passes this replaces moved the intermediate map through HBM and ran their row walk at ~2 TB/s.
+// The vertical weights are block-uniform: re-indexed on the patch rows (zero outside an output's band) they
+// sit in SGPRs and the row walk has only static register indices.
+template <typename T, int TY, int TX, int SY, int SX, int OH, int OW>
+__global__ __launch_bounds__(NT) void resample_tile_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                           const int* __restrict__ sy, const float* __restrict__ wy,
+                                                           const int* __restrict__ sx, const float* __restrict__ wx,
+                                                           int H, int W, int Ho, int Wo, int C, int CVB, int tiles_x) {
+  constexpr int PH = SY * (OH - 1) + TY, PW = SX * (OW - 1) + TX;
+  extern __shared__ float sm[];  // [OH][PW][2][CVB][4]
+  const int chunk = blockIdx.x / tiles_x, tx_ = blockIdx.x - chunk * tiles_x;
+  const int ox0 = tx_ * OW, oy0 = blockIdx.y * OH, b = blockIdx.z;
+  const int y_start = sy[oy0], x_start = sx[ox0];
+  // vertical weights of the OH output rows on the PH patch rows (block-uniform -> scalar registers)
+  float cy[OH][PH];
+#pragma unroll
+  for (int o = 0; o < OH; ++o) {
+    const int oy = min(oy0 + o, Ho - 1);
+    const int off = sy[oy] - y_start;  // 0 .. SY * o
+#pragma unroll
+    for (int k = 0; k < PH; ++k) {
+      const int t = k - off;
+      cy[o][k] = (t >= 0 && t < TY) ? wy[oy * TY + t] : 0.f;
+    }
+  }
+  const T* base = x + ((size_t)b * H * W) * C + (size_t)chunk * CVB * 8;
+  f32x4* sm4 = reinterpret_cast<f32x4*>(sm);
+  // ---- phase A -------------------------------------------------------------------------------------
+  for (int item = threadIdx.x; item < PW * CVB; item += NT) {
+    const int pc = item / CVB, cv = item - pc * CVB;
+    const int ix = min(x_start + pc, W - 1);
+    float acc[OH][8];
+#pragma unroll
+    for (int o = 0; o < OH; ++o)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[o][i] = 0.f;
+    float v[PH][8];
+#pragma unroll
+    for (int r = 0; r < PH; ++r) load8(base + ((size_t)min(y_start + r, H - 1) * W + ix) * C + cv * 8, v[r]);
+#pragma unroll
+    for (int r = 0; r < PH; ++r)
+#pragma unroll
+      for (int o = 0; o < OH; ++o)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[o][i] += cy[o][r] * v[r][i];
+#pragma unroll
+    for (int o = 0; o < OH; ++o) {
+      f32x4* dst = sm4 + ((size_t)(o * PW + pc) * 2) * CVB + cv;
+      dst[0] = f32x4{acc[o][0], acc[o][1], acc[o][2], acc[o][3]};
+      dst[CVB] = f32x4{acc[o][4], acc[o][5], acc[o][6], acc[o][7]};
+    }
+  }
+  __syncthreads();
+  // ---- phase B -------------------------------------------------------------------------------------
+  for (int item = threadIdx.x; item < OH * OW * CVB; item += NT) {
+    const int cv = item % CVB, r_ = item / CVB;
+    const int oxl = r_ % OW, o = r_ / OW;
+    const int gx = ox0 + oxl, gy = oy0 + o;
+    if (gx >= Wo || gy >= Ho) continue;
+    const int offx = sx[gx] - x_start;  // 0 .. SX * oxl
+    float out[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = 0.f;
+#pragma unroll
+    for (int t = 0; t < TX; ++t) {
+      const float w = wx[gx * TX + t];
+      const f32x4* src = sm4 + ((size_t)(o * PW + offx + t) * 2) * CVB + cv;
+      const f32x4 lo = src[0], hi = src[CVB];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { out[i] += w * lo[i]; out[4 + i] += w * hi[i]; }
+    }
+    store8(y + (((size_t)b * Ho + gy) * Wo + gx) * C + (size_t)chunk * CVB * 8 + cv * 8, out);
   }
 }
 
@@ -771,7 +901,7 @@ void close(int slot, hipStream_t s) {
 
 extern "C" {
 
-int o2m_abi_version(void) { return 17; }
+int o2m_abi_version(void) { return 18; }
 
 int32_t o2m_launch_timing(int32_t enable) {
   std::lock_guard<std::mutex> lock(o2m_timing::g_mu);
@@ -889,20 +1019,33 @@ int o2m_act_bwd_reduce(const void* g, const void* y, const void* residual, const
 }
 
 int o2m_fold_scale_dot(const void* gpad, const void* x, const float* scale, void* gx, float* dots,
-                       void* xs, int32_t B, int32_t H, int32_t W, int32_t C, int32_t pad, int32_t dtype,
+                       void* xs, const void* gres, int32_t act, const float* act_mul, float* act_sums,
+                       int32_t B, int32_t H, int32_t W, int32_t C, int32_t pad, int32_t dtype,
                        float* partials, void* stream) {
   if (!gpad || !gx || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7) || C > 8 * NT || pad < 0)
     return O2M_ERR_BAD_ARG;
   if (pad >= H || pad >= W || (dots && !x) || (xs && !dots)) return O2M_ERR_BAD_ARG;
+  if (act_sums && (!x || act == O2M_ACT_TANH)) return O2M_ERR_BAD_ARG;  // the fused activation reads its output x
+  if (!act_sums && (act_mul || act != O2M_ACT_NONE)) return O2M_ERR_BAD_ARG;
   ChanGeom gm = chan_geom(B, H * W, C);
-  const size_t lds = (size_t)gm.PL * gm.CV * 8 * sizeof(float);
+  const size_t lds = (size_t)gm.PL * gm.CV * (act_sums ? 24 : 8) * sizeof(float);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(fold_scale_dot_kernel<T>, dim3(gm.nchunks, B), dim3(NT), lds, s,
-                                       (const T*)gpad, (const T*)x, scale, (T*)gx, dots, (T*)xs,
-                                       dots ? partials : nullptr, H, W, C, pad, gm));
+  float* part = (dots || act_sums) ? partials : nullptr;
+  if (act_sums) {
+    DISPATCH_T(dtype, hipLaunchKernelGGL((fold_scale_dot_kernel<T, true>), dim3(gm.nchunks, B), dim3(NT), lds, s,
+                                         (const T*)gpad, (const T*)x, scale, (T*)gx, dots, (T*)xs, (const T*)gres,
+                                         act_mul, act_sums, part, H, W, C, pad, act, gm));
+  } else {
+    DISPATCH_T(dtype, hipLaunchKernelGGL((fold_scale_dot_kernel<T, false>), dim3(gm.nchunks, B), dim3(NT), lds, s,
+                                         (const T*)gpad, (const T*)x, scale, (T*)gx, dots, (T*)xs, (const T*)gres,
+                                         act_mul, act_sums, part, H, W, C, pad, act, gm));
+  }
   O2M_LAUNCH_CHECK();
-  if (dots && partials) {
-    hipLaunchKernelGGL(chunk_sum_kernel, dim3(B), dim3(NT), 0, s, dots, partials, gm.nchunks, C);
+  if (part && act_sums) {
+    hipLaunchKernelGGL(chunk_sum3_kernel, dim3(B), dim3(NT), 0, s, dots, act_sums, part, gm.nchunks, C);
+    O2M_LAUNCH_CHECK();
+  } else if (part) {
+    hipLaunchKernelGGL(chunk_sum_kernel, dim3(B), dim3(NT), 0, s, dots, part, gm.nchunks, C);
     O2M_LAUNCH_CHECK();
   }
   return 0;
@@ -983,6 +1126,22 @@ int o2m_resample2d(const void* x, void* y, const int32_t* sy, const float* wy, c
     return O2M_ERR_BAD_ARG;
   const long nvec = (long)B * Ho * Wo * (C / 8);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  // tile kernel (LDS, separable in one launch) for the 6-tap transposed upsample
+  if (Ty == 6 && Tx == 6 && span_y >= 1 && span_y <= 2 && span_x >= 1 && span_x <= 2 && B <= 65535) {
+    constexpr int OH = 4, OW = 6, PW = 2 * (OW - 1) + 6;
+    const int CV = C / 8;
+    int CVB = CV < 16 ? CV : 16;
+    while (CV % CVB) --CVB;
+    const int tiles_x = (Wo + OW - 1) / OW, tiles_y = (Ho + OH - 1) / OH;
+    if (tiles_y <= 65535) {
+      const size_t lds = (size_t)OH * PW * 2 * CVB * 16;
+      const dim3 grid((unsigned)(tiles_x * (CV / CVB)), (unsigned)tiles_y, (unsigned)B);
+      DISPATCH_T(dtype, hipLaunchKernelGGL((resample_tile_kernel<T, 6, 6, 2, 2, OH, OW>), grid, dim3(NT), lds, s,
+                                           (const T*)x, (T*)y, sy, wy, sx, wx, H, W, Ho, Wo, C, CVB, tiles_x));
+      O2M_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   // 2x2-block kernel for the operators the model uses; anything else takes the per-output kernel
   if (span_y >= 1 && span_x >= 1 && B <= 65535 && (Ho + 1) / 2 <= 65535) {
     const dim3 grid((unsigned)((((long)(Wo + 1) / 2) * (C / 8) + NT - 1) / NT), (unsigned)((Ho + 1) / 2), (unsigned)B);

@@ -91,9 +91,9 @@ inline void done(int err, const char* op, bool meta) {
 
 void conv2d_fwd(const Tensor& x, const Tensor& w, Tensor& y, const OptT& in_scale, const OptT& out_scale,
                 const OptT& bias, const OptT& residual, int64_t pad, int64_t pad_mode, int64_t act,
-                bool per_sample_w, int64_t stride, const std::optional<Tensor>& stats, const OptT& deq) {
+                bool per_sample_w, int64_t stride, const std::optional<Tensor>& stats, const OptT& deq, const OptT& aux) {
   const char* op = "o2m::conv2d_fwd";
-  chk_f32(stats, op, "stats"); chk_f32(deq, op, "deq");
+  chk_f32(stats, op, "stats"); chk_f32(deq, op, "deq"); chk(aux, op, "aux");
   const bool f8 = is_fp8(x);
   chk(x, op, "x"); chk(w, op, "w"); chk(y, op, "y"); chk(residual, op, "residual");
   chk_f32(in_scale, op, "in_scale"); chk_f32(out_scale, op, "out_scale"); chk_f32(bias, op, "bias");
@@ -136,7 +136,22 @@ void conv2d_fwd(const Tensor& x, const Tensor& w, Tensor& y, const OptT& in_scal
     TORCH_CHECK(stats->numel() >= (x.size(0) * Ho * Wo / rows) * Co * 2, op, ": stats workspace too small");
     d.stats = ptr<float>(stats);
   }
+  if (aux.has_value()) {  // style-dot partials instead of InstanceNorm moments (O2M_STATS_DOT)
+    TORCH_CHECK(stats.has_value(), op, ": aux needs the stats workspace");
+    TORCH_CHECK(aux->sizes() == y.sizes() && aux->scalar_type() == y.scalar_type(), op, ": aux must have y's shape and dtype");
+    d.aux = ptr(aux);
+    d.stats_mode = O2M_STATS_DOT;
+  }
   O2M_CALL(op, x, o2m_conv2d_fwd(&d, stream));
+}
+
+void conv2d_dots_finalize(const Tensor& partial, Tensor& dots, int64_t nchunks) {
+  const char* op = "o2m::conv2d_dots_finalize";
+  chk_f32(partial, op, "partial"); chk_f32(dots, op, "dots");
+  TORCH_CHECK(dots.dim() == 2 && nchunks > 0 && partial.numel() >= dots.numel() * nchunks * 2, op,
+              ": dots is [B][C]; partial holds [B][nchunks][C][2]");
+  O2M_CALL(op, dots, o2m_conv2d_dots_finalize(ptr<float>(partial), ptr<float>(dots), i32(dots.size(0), op), i32(dots.size(1), op),
+                                             i32(nchunks, op), stream));
 }
 
 int64_t conv2d_stats_rows(const Tensor& x, const Tensor& w, const Tensor& y, int64_t pad, int64_t stride) {
@@ -304,23 +319,30 @@ void act_bwd_reduce(const Tensor& g, const OptT& y, const OptT& residual, const 
 }
 
 void fold_scale_dot(const Tensor& gpad, const OptT& x, const OptT& scale, Tensor& gx, const std::optional<Tensor>& dots, int64_t pad,
-                    const std::optional<Tensor>& xs, const std::optional<Tensor>& partials) {
+                    const std::optional<Tensor>& xs, const OptT& gres, int64_t act, const OptT& act_mul,
+                    const std::optional<Tensor>& act_sums, const std::optional<Tensor>& partials) {
   const char* op = "o2m::fold_scale_dot";
   chk(gpad, op, "gpad"); chk(x, op, "x"); chk_f32(scale, op, "scale"); chk(gx, op, "gx"); chk_f32(dots, op, "dots"); chk(xs, op, "xs");
+  chk(gres, op, "gres"); chk_f32(act_mul, op, "act_mul"); chk_f32(act_sums, op, "act_sums");
   TORCH_CHECK(gx.dim() == 4 && gpad.dim() == 4, op, ": gpad, gx are NHWC");
   same_dtype(gx, gpad, op, "gx", "gpad"); same_dtype(gx, x, op, "gx", "x"); same_dtype(gx, xs, op, "gx", "xs");
+  same_dtype(gx, gres, op, "gx", "gres");
   TORCH_CHECK(gpad.size(0) == gx.size(0) && gpad.size(1) == gx.size(1) + 2 * pad && gpad.size(2) == gx.size(2) + 2 * pad &&
                   gpad.size(3) == gx.size(3), op, ": gpad must be gx's shape plus the padding margins");
   TORCH_CHECK(!x.has_value() || x->sizes() == gx.sizes(), op, ": x must have gx's shape");
   TORCH_CHECK(!xs.has_value() || xs->sizes() == gx.sizes(), op, ": xs must have gx's shape");
+  TORCH_CHECK(!gres.has_value() || gres->sizes() == gx.sizes(), op, ": gres must have gx's shape");
+  TORCH_CHECK(!act_sums.has_value() || act_sums->numel() == gx.size(0) * 2 * gx.size(3), op, ": act_sums is [B][2][C]");
+  TORCH_CHECK(!act_mul.has_value() || act_mul->numel() == gx.size(0) * gx.size(3), op, ": act_mul is [B][C]");
   chk_f32(partials, op, "partials");
   TORCH_CHECK(!partials.has_value() ||
-                  partials->numel() >= static_cast<int64_t>(o2m_chan_partials_floats(gx.size(0), gx.size(1) * gx.size(2), gx.size(3), 1)),
+                  partials->numel() >= static_cast<int64_t>(o2m_chan_partials_floats(gx.size(0), gx.size(1) * gx.size(2), gx.size(3),
+                                                                                     act_sums.has_value() ? 3 : 1)),
               op, ": partials workspace too small");
   const int dt_gx = dtype_code(gx, op);
-  O2M_CALL(op, gx, o2m_fold_scale_dot(ptr(gpad), ptr(x), fptr(scale), ptr(gx), ptr<float>(dots), ptr(xs), i32(gx.size(0), op),
-                                     i32(gx.size(1), op), i32(gx.size(2), op), i32(gx.size(3), op), i32(pad, op), dt_gx,
-                                     ptr<float>(partials), stream));
+  O2M_CALL(op, gx, o2m_fold_scale_dot(ptr(gpad), ptr(x), fptr(scale), ptr(gx), ptr<float>(dots), ptr(xs), ptr(gres), i32(act, op),
+                                     fptr(act_mul), ptr<float>(act_sums), i32(gx.size(0), op), i32(gx.size(1), op),
+                                     i32(gx.size(2), op), i32(gx.size(3), op), i32(pad, op), dt_gx, ptr<float>(partials), stream));
 }
 
 int64_t chan_partials_floats(int64_t B, int64_t P, int64_t C, int64_t nv) {
@@ -516,7 +538,8 @@ TORCH_LIBRARY(o2m, m) {
   m.def("instnorm_ws_floats(int B, int P, int C) -> int", &instnorm_ws_floats);
   m.def("reduce_blocks(int n) -> int", &reduce_blocks);
   m.def("conv2d_fwd(Tensor x, Tensor w, Tensor(a!) y, Tensor? in_scale, Tensor? out_scale, Tensor? bias, Tensor? residual, "
-        "int pad, int pad_mode, int act, bool per_sample_w, int stride, Tensor(b!)? stats=None, Tensor? deq=None) -> ()");
+        "int pad, int pad_mode, int act, bool per_sample_w, int stride, Tensor(b!)? stats=None, Tensor? deq=None, Tensor? aux=None) -> ()");
+  m.def("conv2d_dots_finalize(Tensor partial, Tensor(a!) dots, int nchunks) -> ()");
   m.def("amax(Tensor x, Tensor(a!) amax) -> ()");
   m.def("quantize_fp8(Tensor x, Tensor amax, Tensor(a!) y, Tensor(b!) deq) -> ()");
   m.def("conv2d_stats_rows(Tensor x, Tensor w, Tensor y, int pad, int stride) -> int");
@@ -531,7 +554,8 @@ TORCH_LIBRARY(o2m, m) {
   m.def("style_bwd(Tensor? sums, Tensor? bias, Tensor? dots, Tensor s, Tensor? d, Tensor? q, Tensor w, Tensor ws, Tensor(a!)? e, "
         "Tensor(b!) gs, Tensor(c!) gw, Tensor(d!) gws, Tensor(e!) gbs, Tensor(f!)? gq, int ci, float cs, bool accumulate) -> ()");
   m.def("act_bwd_reduce(Tensor g, Tensor? y, Tensor? residual, Tensor? out_mul, Tensor(a!)? gu, Tensor(b!)? sums, int act, Tensor(c!)? partials=None) -> ()");
-  m.def("fold_scale_dot(Tensor gpad, Tensor? x, Tensor? scale, Tensor(a!) gx, Tensor(b!)? dots, int pad, Tensor(c!)? xs, Tensor(d!)? partials=None) -> ()");
+  m.def("fold_scale_dot(Tensor gpad, Tensor? x, Tensor? scale, Tensor(a!) gx, Tensor(b!)? dots, int pad, Tensor(c!)? xs, Tensor? gres=None, "
+        "int act=0, Tensor? act_mul=None, Tensor(d!)? act_sums=None, Tensor(e!)? partials=None) -> ()");
   m.def("chan_partials_floats(int B, int P, int C, int nv) -> int", &chan_partials_floats);
   m.def("instnorm_stats(Tensor x, Tensor(a!) partial, Tensor(b!) mean_rstd, float eps) -> ()");
   m.def("instnorm_apply(Tensor x, Tensor mean_rstd, Tensor? residual, Tensor(a!) y, int act) -> ()");
@@ -568,6 +592,7 @@ TORCH_LIBRARY(o2m, m) {
   m.impl("instnorm_stats", &instnorm_stats);      \
   m.impl("instnorm_finalize", &instnorm_finalize); \
   m.impl("conv2d_stats_rows", &conv2d_stats_rows); \
+  m.impl("conv2d_dots_finalize", &conv2d_dots_finalize); \
   m.impl("instnorm_apply", &instnorm_apply);      \
   m.impl("instnorm_bwd", &instnorm_bwd);          \
   m.impl("resample2d", &resample2d);              \

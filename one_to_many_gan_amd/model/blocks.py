@@ -44,8 +44,9 @@ class ResnetBlock(nn.Module):
             _Slot("InstanceNorm2d (+ residual add) -> instnorm kernels"))
 
     def run(self, t):
-        u = self.conv_block[1].run_norm_act(t, reflect=1, act=H.ACT_RELU)
-        return self.conv_block[5].run_norm_act(u, reflect=1, act=H.ACT_NONE, residual=t)
+        link = ops.BlockLink()  # the residual's gradient is added by the first conv's fold kernel
+        u = self.conv_block[1].run_norm_act(t, reflect=1, act=H.ACT_RELU, head_link=link)
+        return self.conv_block[5].run_norm_act(u, reflect=1, act=H.ACT_NONE, residual=t, tail_link=link)
 
     def forward(self, x: torch.Tensor):
         return ops.to_public(self.run(ops.to_internal(x)), self.dim)
@@ -67,8 +68,12 @@ class ModulatedResnetBlock(nn.Module):
             _Slot("ReflectionPad2d(1) -> conv loader"), modconv3()])
 
     def run(self, t, w):
-        u = self.conv_block[1].run(t, w, reflect=1, act=H.ACT_RELU)
-        return self.conv_block[4].run(u, w, reflect=1, residual=t)
+        # u is consumed by the second conv only and t reaches its residual unchanged: the backward of the two
+        # convs is chained through a BlockLink (residual gradient added by the first conv's fold kernel; the
+        # second conv's fold fused with the first conv's ReLU backward)
+        link = ops.BlockLink(fuse_act=True)
+        u = self.conv_block[1].run(t, w, reflect=1, act=H.ACT_RELU, link=link)
+        return self.conv_block[4].run(u, w, reflect=1, residual=t, link=link)
 
     def forward(self, x: torch.Tensor, w: torch.Tensor):
         return ops.to_public(self.run(ops.to_internal(x), w), self.dim)

@@ -80,19 +80,21 @@ class EqualisedConv2d(nn.Module):
             self._prep = ops.PreparedWeight(self.weight.weight, need_q=False)
         return self._prep
 
-    def run(self, t, *, reflect: int = 0, act: int = H.ACT_NONE, residual=None, norm_eps=None):
+    def run(self, t, *, reflect: int = 0, act: int = H.ACT_NONE, residual=None, norm_eps=None, link=None):
         if reflect and self.padding:
             raise ValueError("reflect padding replaces an external ReflectionPad2d: padding must be 0")
         return ops.conv2d(
             t, self.weight.weight, self.bias if self.use_bias else None, self._prepared(),
             pad=reflect or self.padding, pad_mode=H.PAD_REFLECT if reflect else H.PAD_ZERO,
-            act=act, residual=residual, norm_eps=norm_eps)
+            act=act, residual=residual, norm_eps=norm_eps, link=link)
 
-    def run_norm_act(self, t, *, reflect: int = 0, act: int = H.ACT_NONE, residual=None, eps: float = 1e-5):
+    def run_norm_act(self, t, *, reflect: int = 0, act: int = H.ACT_NONE, residual=None, eps: float = 1e-5,
+                     head_link=None, tail_link=None):
         """conv -> InstanceNorm2d -> activation (+ residual), the statistics coming out of the conv's
-        epilogue (builder.py:162-165,170-173,272-282; blocks.py:21-27)."""
-        y, stats = self.run(t, reflect=reflect, norm_eps=eps)
-        return ops.instance_norm_act(y, act, residual=residual, eps=eps, stats=stats)
+        epilogue (builder.py:162-165,170-173,272-282; blocks.py:21-27).  ``head_link``: this conv consumes a
+        residual block's input first; ``tail_link``: this norm adds that block's residual (ops.BlockLink)."""
+        y, stats = self.run(t, reflect=reflect, norm_eps=eps, link=head_link)
+        return ops.instance_norm_act(y, act, residual=residual, eps=eps, stats=stats, link=tail_link)
 
     def forward(self, x: torch.Tensor):
         return ops.to_public(self.run(ops.to_internal(x)), self.out_features)
@@ -123,14 +125,14 @@ class Conv2dWeightModulate(nn.Module):
             self._prep = ops.PreparedWeight(self.weight.weight, need_q=True)
         return self._prep
 
-    def run(self, t, w, *, reflect: int = 0, act: int = H.ACT_NONE, residual=None):
+    def run(self, t, w, *, reflect: int = 0, act: int = H.ACT_NONE, residual=None, link=None):
         if reflect and self.padding:
             raise ValueError("reflect padding replaces an external ReflectionPad2d: padding must be 0")
         return ops.conv2d(
             t, self.weight.weight, self.bias if self.use_bias else None, self._prepared(),
             pad=reflect or self.padding, pad_mode=H.PAD_REFLECT if reflect else H.PAD_ZERO,
             act=act, style=(w, self.to_style.weight.weight, self.to_style.bias), residual=residual,
-            demodulate=self.demodulate, eps=self.eps)
+            demodulate=self.demodulate, eps=self.eps, link=link)
 
     def forward(self, x: torch.Tensor, w: torch.Tensor):
         return ops.to_public(self.run(ops.to_internal(x), w), self.out_features)

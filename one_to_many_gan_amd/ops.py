@@ -469,13 +469,48 @@ def _pad_cols(t: torch.Tensor, n: int) -> torch.Tensor:
 # ---------------------------------------------------------------------------------- conv
 
 
+# O2M_WGRAD_XS=1: the modulated input x * s for the weight gradient as a stored by-product of fold_scale_dot (the
+# round-2 form) instead of the weight-gradient kernel scaling x on its way into LDS (in_scale): one tensor write on
+# the main stream against a few more VALU instructions per staged vector on the weight-gradient stream.
+_WGRAD_XS = _os.environ.get("O2M_WGRAD_XS", "0") == "1"
+# O2M_FUSED_DGRAD_DOT=0: zero-padded modulated convs run fold_scale_dot behind their data gradient (round-2 form)
+# instead of taking the style scale and the style dot out of the data-gradient epilogue (O2M_STATS_DOT)
+_FUSED_DGRAD_DOT = _os.environ.get("O2M_FUSED_DGRAD_DOT", "1") == "1"
+# O2M_BLOCK_LINK=0: residual-block backward without the links below (autograd adds the residual gradient, every
+# conv runs its own act_bwd_reduce and fold_scale_dot)
+_BLOCK_LINK = _os.environ.get("O2M_BLOCK_LINK", "1") == "1"
+
+
+class BlockLink:
+    """Backward-time hand-offs inside a residual block ``x + conv_b(act(conv_a(x)))`` (blocks.py:36-68), shared by
+    the two ``_ConvFn`` calls of one block application:
+
+    * ``res_grad``: conv_b adds the residual x, so dL/d(out) also flows to x unchanged.  Instead of returning it
+      to autograd (one elementwise add of two activation-sized tensors per block), conv_b parks it here and
+      conv_a's fold_scale_dot adds it while writing its own data gradient (``gres``).
+    * ``deferred``: conv_b's input IS conv_a's output u = act(...).  conv_b stops after its data-gradient GEMM
+      and parks the padded gradient here; conv_a then runs ONE kernel that folds / scales it, forms conv_b's style
+      dot, applies conv_a's activation backward and demodulation and adds conv_a's sums -- the gradient of u is
+      never stored (4 tensor passes instead of 7).  conv_b's style backward (which needs that dot) runs right
+      after, from the closure parked with it.
+
+    Valid only while u has no other consumer than conv_b and x reaches conv_b's residual unchanged, which the
+    block guarantees; a gradient for u from anywhere else makes conv_a raise instead of silently using it."""
+
+    def __init__(self, fuse_act: bool = False):
+        self.fuse_act = fuse_act  # conv_b may park its fold for conv_a (u has no other consumer)
+        self.res_grad = None
+        self.deferred = None
+        self.lazy_ptr = None
+
+
 class _ConvFn(torch.autograd.Function):
     """y = act(d[b,o] * conv(W*c, pad(x * s[b,i])) + bias) + residual with
     s = to_style(w_style) and d = demodulation (both computed by o2m_style_fwd)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, w_style, ts_weight, ts_bias, residual, prep, pad, pad_mode, act,
-                demodulate, eps, stats_eps):
+                demodulate, eps, stats_eps, link=None):
         w_f, w_d, q, w32, qt = prep.get()
         B, Hh, Ww, cip = x.shape
         if cip != prep.cip:
@@ -552,6 +587,7 @@ class _ConvFn(torch.autograd.Function):
             H.conv2d_fwd(x, w_f, y, in_scale=s, out_scale=d, bias=bias_p, residual=residual,
                          pad=pad, pad_mode=pad_mode, act=act)
         ctx.prep, ctx.pad, ctx.pad_mode, ctx.act = prep, pad, pad_mode, act
+        ctx.link = link if _BLOCK_LINK else None
         ctx.norm_follows = stats_eps is not None
         ctx.counted = prep.note_forward_use(ctx.needs_input_grad[1])
         ctx.ts_params = (ts_weight, ts_bias)
@@ -573,16 +609,46 @@ class _ConvFn(torch.autograd.Function):
         need_s = s is not None and any(ctx.needs_input_grad[3:6])
         need_res = ctx.needs_input_grad[6]
         dev = g.device
+        link = ctx.link
+        head = link is not None and not ctx.has_res   # first conv of a residual block
+        tail = link is not None and ctx.has_res       # the conv that adds the block's residual
+        deferred = None
+        if head and link.deferred is not None:
+            deferred, link.deferred = link.deferred, None
+            if g.data_ptr() != link.lazy_ptr:
+                raise RuntimeError("BlockLink: the gradient of a block's inner activation arrived from outside the "
+                                   "block (the deferred fold would be lost)")
 
-        sums = dots = None
         want_sums = act != H.ACT_NONE or d is not None or (ctx.has_bias and need_b and not ctx.norm_follows)
+        run_style = s is not None and (need_s or (need_w and d is not None))
         want_dots = s is not None and (need_x or need_s or (need_w and d is not None))
-        if want_sums or want_dots:  # one zero-fill for both atomically accumulated tables
-            ns, nd = (B * 2 * prep.cop if want_sums else 0), (B * cip if want_dots else 0)
+        # data gradient of a zero-padded modulated conv: style scale and style dot out of the GEMM's epilogue
+        kpad = prep.kh - 1 - (0 if pad_mode == H.PAD_REFLECT else pad)
+        hp = Hh + (2 * pad if pad_mode == H.PAD_REFLECT else 0)
+        wp = Ww + (2 * pad if pad_mode == H.PAD_REFLECT else 0)
+        fuse_dot = (_FUSED_DGRAD_DOT and s is not None and pad_mode == H.PAD_ZERO and (need_x or need_s)
+                    and not prep.fp8_ok(True, B * hp * wp))
+        dot_rows = 0
+        if fuse_dot:
+            dot_rows = H.conv2d_stats_rows(g, w_d, x, pad=kpad)
+            fuse_dot = dot_rows > 0
+        sums = dots = None
+        if want_sums or (want_dots and not fuse_dot):  # one zero-fill for both atomically accumulated tables
+            ns = B * 2 * prep.cop if want_sums else 0
+            nd = B * cip if (want_dots and not fuse_dot) else 0
             z = ZERO_POOL.take(ns + nd, dev)
             sums = z[:ns].view(B, 2, prep.cop) if want_sums else None
-            dots = z[ns:].view(B, cip) if want_dots else None
-        if act != H.ACT_NONE or d is not None:
+            dots = z[ns:].view(B, cip) if nd else None
+
+        # ---- 1. gradient of the GEMM result: activation backward, demodulation folded in -------------------
+        if deferred is not None:
+            # the block's second conv parked its padded data gradient: fold + its style scale + its style dot
+            # + THIS conv's activation backward and sums in one pass over (padded gradient, u)
+            gu = torch.empty_like(g)
+            H.fold_scale_dot(deferred["gxp"], y, deferred["s"], gu, deferred["dots"], deferred["pad"],
+                             act=act, act_mul=d, act_sums=sums)
+            deferred["finish"]()
+        elif act != H.ACT_NONE or d is not None:
             gu = torch.empty_like(g)
             # u = y - residual = act(pre); the stored tensor is gu * d (demodulation folded in)
             H.act_bwd_reduce(g, y, residual, d, gu, sums, act)
@@ -601,29 +667,54 @@ class _ConvFn(torch.autograd.Function):
             tot = sums[:, 0].sum(0)
             g_bias = tot[: prep.co].to(weight.dtype)
 
-        g_x = xs = None
-        if need_x or need_s:
-            kpad = prep.kh - 1 - (0 if pad_mode == H.PAD_REFLECT else pad)
-            hp = Hh + (2 * pad if pad_mode == H.PAD_REFLECT else 0)
-            wp = Ww + (2 * pad if pad_mode == H.PAD_REFLECT else 0)
-            gxp = torch.empty((B, hp, wp, cip), dtype=g.dtype, device=dev)
-            if prep.fp8_ok(True, B * hp * wp):  # e5m2 gradients x e4m3 filter
-                w8, rec = prep.get_fp8(True)
-                H.conv2d_fwd(_quantize(gu, torch.float8_e5m2, rec[0:2]), w8, gxp, pad=kpad, pad_mode=H.PAD_ZERO,
-                             act=H.ACT_NONE, deq=rec)
-            else:
-                H.conv2d_fwd(gu, w_d, gxp, pad=kpad, pad_mode=H.PAD_ZERO, act=H.ACT_NONE)
-            if s is not None or pad_mode == H.PAD_REFLECT:
-                g_x = torch.empty_like(x)
-                if s is not None:
-                    if need_w:  # x * s for the weight gradient, written while x is being read
-                        xs = torch.empty_like(x)
-                H.fold_scale_dot(gxp, x if s is not None else None, s, g_x, dots,
-                                 pad if pad_mode == H.PAD_REFLECT else 0, xs=xs)
-            else:
-                g_x = gxp
+        # ---- 2. data gradient ---------------------------------------------------------------------------
+        res_in = None
+        if head and link.res_grad is not None:
+            res_in, link.res_grad = link.res_grad, None
+        g_res = g if (ctx.has_res and need_res) else None
+        if tail and g_res is not None and need_x:
+            link.res_grad, g_res = g_res, None  # the block's first conv adds it to its data gradient
 
-        run_style = s is not None and (need_s or (need_w and d is not None))
+        g_x = xs = None
+        defer_fold = False
+        if need_x or need_s:
+            if fuse_dot:
+                nchunks = hp * wp // dot_rows
+                part = torch.empty(B * nchunks * cip * 2, dtype=torch.float32, device=dev)
+                g_x = torch.empty_like(x)
+                H.conv2d_fwd(gu, w_d, g_x, out_scale=s, pad=kpad, pad_mode=H.PAD_ZERO, act=H.ACT_NONE,
+                             stats=part, aux=x)
+                dots = torch.empty((B, cip), dtype=torch.float32, device=dev)
+                H.conv2d_dots_finalize(part, dots, nchunks)
+            else:
+                gxp = torch.empty((B, hp, wp, cip), dtype=g.dtype, device=dev)
+                if prep.fp8_ok(True, B * hp * wp):  # e5m2 gradients x e4m3 filter
+                    w8, rec = prep.get_fp8(True)
+                    H.conv2d_fwd(_quantize(gu, torch.float8_e5m2, rec[0:2]), w8, gxp, pad=kpad, pad_mode=H.PAD_ZERO,
+                                 act=H.ACT_NONE, deq=rec)
+                else:
+                    H.conv2d_fwd(gu, w_d, gxp, pad=kpad, pad_mode=H.PAD_ZERO, act=H.ACT_NONE)
+                if s is not None or pad_mode == H.PAD_REFLECT:
+                    # the block's first conv finishes this (BlockLink.deferred) when it can fuse its activation
+                    # backward: its output is this conv's input, and nothing else wants dL/dx
+                    defer_fold = (tail and link.fuse_act and s is not None and need_x
+                                  and not (_WGRAD_XS and need_w))
+                    if defer_fold:
+                        g_x = torch.empty_like(x)  # never read: the head checks that it gets exactly this back
+                        link.lazy_ptr = g_x.data_ptr()
+                    else:
+                        g_x = torch.empty_like(x)
+                        if s is not None and need_w and _WGRAD_XS:
+                            xs = torch.empty_like(x)  # x * s for the weight gradient, written while x is being read
+                        H.fold_scale_dot(gxp, x if s is not None else None, s, g_x, dots,
+                                         pad if pad_mode == H.PAD_REFLECT else 0, xs=xs, gres=res_in)
+                        res_in = None
+                else:
+                    g_x = gxp
+            if res_in is not None:  # no fold pass to carry it (fused epilogue / plain conv)
+                g_x = g_x + res_in
+                res_in = None
+
         ev_pre = None
         if run_style:  # outputs allocated (and sums / dots complete) before the event the side stream waits on
             wd_ = wv.shape[1]
@@ -646,56 +737,67 @@ class _ConvFn(torch.autograd.Function):
             gq_tmp = None
             if d is not None and not need_w:  # dL/dQ is discarded when the filter wants no gradient
                 gq_tmp = torch.zeros((prep.cop, cip), dtype=torch.float32, device=dev)
-            if _side_stream(dev) is not None:
+            if _side_stream(dev) is not None and not defer_fold:
                 ev_pre = torch.cuda.Event()
                 ev_pre.record(torch.cuda.current_stream(dev))
 
+        # ---- 3. weight gradient (own stream) ---------------------------------------------------------------
         gq_acc = None
         if need_w:
             # accumulated in the kernel layout across every use of the layer in this backward;
             # converted into weight.grad once, by _finalize_weight_grads
             dw_acc, gq_acc = prep.accumulators(dev)
-            x_eff = xs if xs is not None else (x if s is None else None)
             wst = _wgrad_stream(dev)
             if wst is not None:
                 ev_w = torch.cuda.Event()
                 ev_w.record(torch.cuda.current_stream(dev))
                 wst.wait_event(ev_w)
-                for t in (x, x_eff, gu, s):  # keep the operands alive until the side stream is done
+                for t in (x, xs, gu, s):  # keep the operands alive until the side stream is done
                     if t is not None:
                         t.record_stream(wst)
             with (torch.cuda.stream(wst) if wst is not None else contextlib.nullcontext()):
                 if s is None and residual is None and prep.s2d_ok(pad, pad_mode, Hh, Ww):
                     prep.s2d_wgrad(x, gu, pad, pad_mode)
-                elif x_eff is not None:
-                    H.conv2d_wgrad(x_eff, gu, dw_acc, pad=pad, pad_mode=pad_mode)
-                else:
+                elif xs is not None:
+                    H.conv2d_wgrad(xs, gu, dw_acc, pad=pad, pad_mode=pad_mode)
+                else:  # plain conv (s None), or the modulated input formed while x is staged (in_scale)
                     H.conv2d_wgrad(x, gu, dw_acc, in_scale=s, pad=pad, pad_mode=pad_mode)
 
-        if run_style:
-            gq = (gq_acc if gq_acc is not None else gq_tmp) if d is not None else None
-            side = _side_stream(dev)
-            if side is not None:  # overlaps the weight-gradient kernel enqueued just above
-                main = torch.cuda.current_stream(dev)
-                side.wait_event(ev_pre)
-                with torch.cuda.stream(side):
+        # ---- 4. style path (B x C sized) -------------------------------------------------------------------
+        def style_and_count():
+            if run_style:
+                gq = (gq_acc if gq_acc is not None else gq_tmp) if d is not None else None
+                side = None if defer_fold else _side_stream(dev)
+                if side is not None:  # overlaps the weight-gradient kernel enqueued just above
+                    main = torch.cuda.current_stream(dev)
+                    side.wait_event(ev_pre)
+                    with torch.cuda.stream(side):
+                        H.style_bwd(sums, bias_p, dots, s, d, q, wv, ws, e, gs, g_ws, g_tw, g_tb, gq, prep.ci,
+                                    1.0 / math.sqrt(wd_), accumulate=direct)
+                        ev_done = torch.cuda.Event()
+                        ev_done.record(side)
+                    main.wait_event(ev_done)
+                else:
                     H.style_bwd(sums, bias_p, dots, s, d, q, wv, ws, e, gs, g_ws, g_tw, g_tb, gq, prep.ci,
                                 1.0 / math.sqrt(wd_), accumulate=direct)
-                    ev_done = torch.cuda.Event()
-                    ev_done.record(side)
-                main.wait_event(ev_done)
-            else:
-                H.style_bwd(sums, bias_p, dots, s, d, q, wv, ws, e, gs, g_ws, g_tw, g_tb, gq, prep.ci,
-                            1.0 / math.sqrt(wd_), accumulate=direct)
+            if need_w and ctx.counted:  # after style_bwd above: it adds this use's dL/dQ
+                prep.use_reduced(dev)
+
+        if defer_fold:
+            # dots is written by the head's fused kernel; the style backward reads it: both run from there.
+            # (g_ws is allocated now and filled then -- before anything downstream of this backward can read it:
+            # the head's backward runs earlier in stream order than any consumer of the style gradients.)
+            link.deferred = {"gxp": gxp, "s": s, "dots": dots, "pad": pad if pad_mode == H.PAD_REFLECT else 0,
+                             "finish": style_and_count}
+        else:
+            style_and_count()
+        if run_style:
             if direct:
                 g_tw = g_tb = None  # already in .grad
         else:
             g_ws = g_tw = g_tb = None
-        if need_w and ctx.counted:  # after style_bwd above: it adds this use's dL/dQ
-            prep.use_reduced(dev)
-        g_res = g if (ctx.has_res and need_res) else None
         return (g_x if need_x else None, None, g_bias, g_ws, g_tw, g_tb, g_res,
-                None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None)
 
 
 # Debug tap (None in production): a list that receives, in execution order, the sign mask of every
@@ -711,13 +813,14 @@ def _tap_activation(y, act, residual):
 
 
 def conv2d(x, weight, bias, prep, *, pad, pad_mode=H.PAD_ZERO, act=H.ACT_NONE, style=None,
-           residual=None, demodulate=True, eps=1e-8, norm_eps=None):
+           residual=None, demodulate=True, eps=1e-8, norm_eps=None, link=None):
     """``style`` = (w, to_style.weight, to_style.bias) for the modulated conv, else None.
     ``norm_eps``: the conv feeds an InstanceNorm with this eps; returns ``(y, mean_rstd)`` with the
-    statistics of y ([B][C][2] fp32) for ``instance_norm_act(..., stats=mean_rstd)``."""
+    statistics of y ([B][C][2] fp32) for ``instance_norm_act(..., stats=mean_rstd)``.
+    ``link``: the BlockLink shared by the two convs of one residual-block application."""
     w_style, ts_w, ts_b = style if style is not None else (None, None, None)
     out = _ConvFn.apply(x, weight, bias, w_style, ts_w, ts_b, residual, prep, pad, pad_mode, act,
-                        demodulate, eps, norm_eps)
+                        demodulate, eps, norm_eps, link)
     if norm_eps is None:
         _tap_activation(out, act, residual)
     return out
@@ -730,7 +833,8 @@ class _InstNormFn(torch.autograd.Function):
     """y = act(InstanceNorm2d(x)) + residual  (eps 1e-5, biased variance, no affine)."""
 
     @staticmethod
-    def forward(ctx, x, residual, act, eps, mr):
+    def forward(ctx, x, residual, act, eps, mr, link=None):
+        ctx.link = link if (_BLOCK_LINK and residual is not None) else None
         B, Hh, Ww, Cn = x.shape
         if mr is None:
             ws = torch.empty(H.instnorm_ws_floats(B, Hh * Ww, Cn), dtype=torch.float32, device=x.device)
@@ -753,12 +857,16 @@ class _InstNormFn(torch.autograd.Function):
             gs = torch.empty((B, Cn, 2), dtype=torch.float32, device=x.device)
             gx = torch.empty_like(x)
             H.instnorm_bwd(g, x, mr, ws, gs, gx, ctx.act)
-        return gx, (g if ctx.needs_input_grad[1] else None), None, None, None
+        g_res = g if ctx.needs_input_grad[1] else None
+        if ctx.link is not None and g_res is not None:
+            ctx.link.res_grad, g_res = g_res, None  # added by the block's first conv (BlockLink)
+        return gx, g_res, None, None, None, None
 
 
-def instance_norm_act(x, act=H.ACT_NONE, residual=None, eps=1e-5, stats=None):
-    """``stats``: mean / rstd of x already computed (by the epilogue of the conv that produced x)."""
-    y = _InstNormFn.apply(x, residual, act, eps, stats)
+def instance_norm_act(x, act=H.ACT_NONE, residual=None, eps=1e-5, stats=None, link=None):
+    """``stats``: mean / rstd of x already computed (by the epilogue of the conv that produced x).
+    ``link``: BlockLink of the residual block this closes (the residual's gradient goes to the block's first conv)."""
+    y = _InstNormFn.apply(x, residual, act, eps, stats, link)
     _tap_activation(y, act, residual)
     return y
 
@@ -826,13 +934,18 @@ def split_batch(t, k):
 # -------------------------------------------------------------------------------- resample
 
 
+# O2M_SPLIT_WIDE_RESAMPLE=1: the 6-tap transposed upsample as a vertical and a horizontal 1-D launch (the round-2
+# form, kept for A/B) instead of the one-launch LDS tile kernel
+_SPLIT_WIDE_RESAMPLE = _os.environ.get("O2M_SPLIT_WIDE_RESAMPLE", "0") == "1"
+
+
 def _apply_taps(x, taps):
-    """One banded 2-D operator on an NHWC buffer.  Wide operators (the 6-tap transposed upsample:
-    36 taps per output in one pass) run as a vertical then a horizontal 1-D pass."""
+    """One banded 2-D operator on an NHWC buffer (the 6-tap transposed upsample -- 36 taps per output -- runs
+    as the separable LDS tile kernel of o2m_resample2d)."""
     sy, wy, sx, wx, T, ho, wo = taps
     B, Hh, Ww, Cn = x.shape
     y = torch.empty((B, ho, wo, Cn), dtype=x.dtype, device=x.device)
-    if int(T) == 6 and T.span_y == 2 and T.span_x == 2:  # the instantiated 1-D kernels
+    if int(T) == 6 and T.span_y == 2 and T.span_x == 2 and _SPLIT_WIDE_RESAMPLE:  # A/B: two 1-D passes
         ix, iwx = R.identity_taps(Ww, x.device)
         iy, iwy = R.identity_taps(ho, x.device)
         mid = torch.empty((B, ho, Ww, Cn), dtype=x.dtype, device=x.device)

@@ -528,3 +528,120 @@ def test_launch_timer_files_every_kernel_of_a_call_under_its_own_name():
     wg = [k for k in stats if k.startswith("conv_wgrad<bf16")]
     assert len(wg) == 1 and stats[wg[0]][2] == rows * per_row and stats["wgrad_reduce"][0] == 1
     assert H.launch_timing_read() == {}  # reading clears the records
+
+
+# ---------------------------------------------------------------------------------- round 3: fused backward forms
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_fold_scale_dot_residual_and_fused_activation_match_the_separate_kernels(dt):
+    """o2m_fold_scale_dot with gres (residual gradient added) and with the fused activation backward of the layer
+    below (act_sums) against the chain it replaces: fold_scale_dot -> elementwise add -> act_bwd_reduce."""
+    from one_to_many_gan_amd import _hip as H
+
+    torch.manual_seed(11)
+    B, S, C, pad = 3, 20, 64, 1
+    gpad = torch.randn(B, S + 2, S + 2, C, device="cuda").to(dt)
+    x = torch.relu(torch.randn(B, S, S, C, device="cuda")).to(dt)  # the output of a ReLU layer
+    s = torch.randn(B, C, device="cuda")
+    dmul = torch.rand(B, C, device="cuda") + 0.5
+    gres = torch.randn(B, S, S, C, device="cuda").to(dt)
+    tol = 1e-6 if dt == torch.float32 else 2e-2
+
+    def rel(a, b):
+        return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+    # separate kernels
+    gx0, dots0 = torch.empty_like(x), torch.zeros(B, C, device="cuda")
+    H.fold_scale_dot(gpad, x, s, gx0, dots0, pad)
+    # (a) residual gradient
+    gx1, dots1 = torch.empty_like(x), torch.zeros(B, C, device="cuda")
+    H.fold_scale_dot(gpad, x, s, gx1, dots1, pad, gres=gres)
+    assert rel(gx1, gx0.float() + gres.float()) < tol
+    assert rel(dots1, dots0) < 1e-5
+    # (b) fused activation backward: reference = act_bwd_reduce on the stored gradient
+    for act in (H.ACT_RELU, H.ACT_LRELU):
+        gu0, sums0 = torch.empty_like(x), torch.zeros(B, 2, C, device="cuda")
+        H.act_bwd_reduce(gx0, x, None, dmul, gu0, sums0, act)
+        gu1, sums1, dots2 = torch.empty_like(x), torch.zeros(B, 2, C, device="cuda"), torch.zeros(B, C, device="cuda")
+        H.fold_scale_dot(gpad, x, s, gu1, dots2, pad, act=act, act_mul=dmul, act_sums=sums1)
+        assert rel(gu1, gu0) < tol, act
+        assert rel(sums1, sums0) < (1e-5 if dt == torch.float32 else 2e-2), act
+        assert rel(dots2, dots0) < 1e-5
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 32, 64, 128), (4, 128, 128, 64, 256), (3, 64, 64, 128, 64)],
+                         ids=["256x64-tile", "p8", "co64"])
+def test_data_gradient_epilogue_emits_style_scale_and_dot(shape):
+    """O2M_STATS_DOT: the data gradient of a zero-padded modulated conv leaves the GEMM epilogue multiplied by the
+    style and with its style dot as row-block partials -- against conv + o2m_fold_scale_dot(pad 0)."""
+    from one_to_many_gan_amd import _hip as H
+
+    torch.manual_seed(12)
+    B, Hh, Ww, Ck, Cn = shape  # reduction channels (the conv's outputs), result channels (the conv's inputs)
+    gu = torch.randn(B, Hh, Ww, Ck, device="cuda").bfloat16()
+    w_d = (torch.randn(Cn, 3, 3, Ck, device="cuda") / (3 * Ck ** 0.5)).bfloat16()
+    x = torch.randn(B, Hh, Ww, Cn, device="cuda").bfloat16()
+    s = torch.randn(B, Cn, device="cuda")
+    gxp = torch.empty(B, Hh, Ww, Cn, device="cuda", dtype=torch.bfloat16)
+    H.conv2d_fwd(gu, w_d, gxp, pad=1, pad_mode=H.PAD_ZERO, act=H.ACT_NONE)
+    gx0, dots0 = torch.empty_like(x), torch.zeros(B, Cn, device="cuda")
+    H.fold_scale_dot(gxp, x, s, gx0, dots0, 0)
+    rows = H.conv2d_stats_rows(gu, w_d, x, pad=1)
+    assert rows > 0 and (Hh * Ww) % rows == 0
+    nchunks = Hh * Ww // rows
+    part = torch.full((B * nchunks * Cn * 2,), float("nan"), device="cuda")
+    gx1, dots1 = torch.empty_like(x), torch.empty(B, Cn, device="cuda")
+    H.conv2d_fwd(gu, w_d, gx1, out_scale=s, pad=1, pad_mode=H.PAD_ZERO, act=H.ACT_NONE, stats=part, aux=x)
+    H.conv2d_dots_finalize(part, dots1, nchunks)
+    torch.cuda.synchronize()
+    # gx0 went through a bf16 rounding of the unscaled gradient first: one bf16 ulp of slack
+    assert float((gx1.double() - gx0.double()).norm() / gx0.double().norm()) < 6e-3
+    # the fused dot uses the fp32 accumulator, the separate one the rounded gradient
+    assert float((dots1.double() - dots0.double()).norm() / dots0.double().norm()) < 5e-3
+    # and against fp64 of the same operands
+    ref = torch.nn.functional.conv2d(gu.double().cpu().permute(0, 3, 1, 2), w_d.double().cpu().permute(0, 3, 1, 2),
+                                     padding=1).permute(0, 2, 3, 1)
+    dref = (ref * x.double().cpu()).sum(dim=(1, 2))
+    assert float((dots1.double().cpu() - dref).norm() / dref.norm()) < 1e-4
+    assert float((gx1.double().cpu() - ref * s.double().cpu()[:, None, None, :]).norm() / ref.norm()) < 6e-3
+
+
+def test_wgrad_in_scale_equals_the_prescaled_input():
+    """The weight-gradient kernel scaling x by the style while staging it (in_scale) against the stored x * s."""
+    from one_to_many_gan_amd import _hip as H
+
+    torch.manual_seed(13)
+    for (B, S, Ci, Co, pad_mode) in ((3, 32, 64, 64, H.PAD_REFLECT), (2, 64, 128, 256, H.PAD_ZERO), (2, 33, 64, 128, H.PAD_ZERO)):
+        x = torch.randn(B, S, S, Ci, device="cuda").bfloat16()
+        g = torch.randn(B, S, S, Co, device="cuda").bfloat16()
+        s = torch.randn(B, Ci, device="cuda")
+        xs = (x.float() * s[:, None, None, :]).bfloat16()
+        a = torch.zeros(Co, 3, 3, Ci, device="cuda")
+        b = torch.zeros_like(a)
+        H.conv2d_wgrad(xs, g, a, pad=1, pad_mode=pad_mode)
+        H.conv2d_wgrad(x, g, b, in_scale=s, pad=1, pad_mode=pad_mode)
+        torch.cuda.synchronize()
+        assert float((a - b).norm() / a.norm()) < 1e-6, (B, S, Ci, Co)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_transposed_upsample_tile_kernel_matches_the_dense_operator(dt):
+    """The one-launch LDS tile kernel of the 6-tap transposed upsample against the dense operator matrices."""
+    from one_to_many_gan_amd import _hip as H
+    from one_to_many_gan_amd import resample as R
+
+    torch.manual_seed(14)
+    for (B, n_h, n_w, C) in ((2, 16, 24, 32), (1, 64, 64, 128), (2, 9, 13, 8), (1, 32, 32, 256)):
+        sy, wy, sx, wx, T, ho, wo = R.taps("up", n_h, n_w, True, torch.device("cuda"))
+        assert int(T) == 6 and (ho, wo) == (n_h, n_w)
+        g = torch.randn(B, 2 * n_h, 2 * n_w, C, device="cuda").to(dt)
+        out = torch.empty(B, ho, wo, C, device="cuda", dtype=dt)
+        H.resample2d(g, out, sy, wy, sx, wx, int(T), int(T), T.span_y, T.span_x)
+        torch.cuda.synchronize()
+        a_h = torch.from_numpy(R.operator_matrix("up", n_h).T.copy())  # [n_h][2 n_h]
+        a_w = torch.from_numpy(R.operator_matrix("up", n_w).T.copy())
+        ref = torch.einsum("ip,bpqc,jq->bijc", a_h, g.double().cpu(), a_w)
+        err = float((out.double().cpu() - ref).norm() / ref.norm())
+        assert err < (1e-6 if dt == torch.float32 else 4e-3), (B, n_h, n_w, C, err)
