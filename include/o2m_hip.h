@@ -125,6 +125,8 @@ typedef struct {
                              partials: the separate o2m_fold_scale_dot pass over the gradient and x (layers.py:152-154
                              backward) is not run.  Requires R > 0, act NONE, no bias, no residual.
                              o2m_conv2d_dots_finalize adds a sample's partials in block order. */
+  void* aux_scaled;       /* O2M_STATS_DOT only, or NULL: receives aux * out_scale[b, o] (y's shape and dtype) -- the
+                             modulated input x * s that o2m_conv2d_wgrad reduces, written while aux is in registers */
 } o2m_conv_desc;
 #define O2M_STATS_MOMENTS 0
 #define O2M_STATS_DOT 1

@@ -44,7 +44,7 @@ class ConvDesc(C.Structure):
                 ("B", _i32), ("H", _i32), ("W", _i32), ("Ci", _i32), ("Co", _i32), ("KH", _i32),
                 ("KW", _i32), ("pad", _i32), ("pad_mode", _i32), ("act", _i32), ("dtype", _i32),
                 ("w_batch_stride", _i32), ("stride", _i32), ("stats_mode", _i32), ("stats", _vp),
-                ("deq_scale", _vp), ("aux", _vp)]
+                ("deq_scale", _vp), ("aux", _vp), ("aux_scaled", _vp)]
 
 
 class WgradDesc(C.Structure):
@@ -193,13 +193,14 @@ def check(err: int, what: str):
 
 
 def conv2d_fwd(x, w, y, *, in_scale=None, out_scale=None, bias=None, residual=None, pad, pad_mode, act,
-               per_sample_w=False, stride=1, stats=None, deq=None, aux=None):
+               per_sample_w=False, stride=1, stats=None, deq=None, aux=None, aux_scaled=None):
     """``stats``: fp32 workspace for the InstanceNorm partial sums of y (see o2m_conv_desc.stats) -- or, with
-    ``aux`` (a tensor of y's shape), for the style-dot partials sum_p acc * aux (O2M_STATS_DOT).
+    ``aux`` (a tensor of y's shape), for the style-dot partials sum_p acc * aux (O2M_STATS_DOT); ``aux_scaled``
+    then optionally receives aux * out_scale.
     ``deq``: fp8 operands (x float8_e4m3fn / float8_e5m2, w float8_e4m3fn): device tensor of the two
     dequantisation factors."""
     return ops().conv2d_fwd(x, w, y, in_scale, out_scale, bias, residual, pad, pad_mode, act, per_sample_w, stride,
-                            stats, deq, aux)
+                            stats, deq, aux, aux_scaled)
 
 
 def conv2d_dots_finalize(partial, dots, nchunks):

@@ -544,6 +544,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
   const bool stream_out = (size_t)M * Co * ES >= ((size_t)64 << 20);
   const bool dot_mode = d.stats && d.stats_mode == O2M_STATS_DOT;
   const T* __restrict__ AUX = static_cast<const T*>(d.aux);
+  T* __restrict__ AUXS = static_cast<T*>(d.aux_scaled);
   const int wpp = d.stats ? 1 : WPP_MAX;  // wave rows per pass
   const int npass = WAVES_M / wpp;
   const int wrow_ = wave / WAVES_N;
@@ -574,8 +575,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
       const f32x4 b = *reinterpret_cast<const f32x4*>(csm + row * CSTR + ec8 * 8 + 4);
       float o[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
       const size_t off = (size_t)m * Co + en;
+      float xv[8];
       if (dot_mode) {  // style dot of the data gradient: sum over pixels of (unscaled result) * aux
-        float xv[8];
         load8x(AUX + off, xv, stream_out);
 #pragma unroll
         for (int q = 0; q < 8; ++q) st[q] += o[q] * xv[q];
@@ -585,10 +586,19 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
         const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 4);
 #pragma unroll
         for (int q = 0; q < 4; ++q) { o[q] *= s0[q]; o[4 + q] *= s1[q]; }
+        if (dot_mode && AUXS) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { xv[q] *= s0[q]; xv[4 + q] *= s1[q]; }
+        }
       } else if (d.out_scale) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) o[q] *= esc[q];
+        if (dot_mode && AUXS) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) xv[q] *= esc[q];
+        }
       }
+      if (dot_mode && AUXS) store8x(AUXS + off, xv, stream_out);  // aux * out_scale: the modulated input x * s
 #pragma unroll
       for (int q = 0; q < 8; ++q) o[q] += ebias[q];
       if (d.stats && !dot_mode) {
@@ -968,6 +978,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
   const bool stream_out = (size_t)M * Co * sizeof(T) >= ((size_t)64 << 20);
   const bool dot_mode = d.stats && d.stats_mode == O2M_STATS_DOT;
   const T* __restrict__ AUX = static_cast<const T*>(d.aux);
+  T* __restrict__ AUXS = static_cast<T*>(d.aux_scaled);
   static_assert(NT % VPR == 0, "one channel vector per thread");
   const int ec8 = tid % VPR, erow = tid / VPR, en = n0 + ec8 * 8;
   const bool ecol_ok = en < Co;
@@ -1019,8 +1030,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
       const f32x4 b = *reinterpret_cast<const f32x4*>(csm + row * CSTR + ec8 * 8 + 4);
       float o[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
       const size_t off = (size_t)m * Co + en;
+      float xv[8];
       if (dot_mode) {  // style dot of the data gradient: sum over pixels of (unscaled result) * aux
-        float xv[8];
         load8x(AUX + off, xv, stream_out);
 #pragma unroll
         for (int q = 0; q < 8; ++q) st[q] += o[q] * deq * xv[q];
@@ -1030,10 +1041,20 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
         const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 4);
 #pragma unroll
         for (int q = 0; q < 4; ++q) { o[q] *= s0[q] * deq; o[4 + q] *= s1[q] * deq; }
+        if (dot_mode && AUXS) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { xv[q] *= s0[q]; xv[4 + q] *= s1[q]; }
+        }
       } else {
 #pragma unroll
         for (int q = 0; q < 8; ++q) o[q] *= esc[q];
+        if (dot_mode && AUXS && d.out_scale) {  // (a one-sample tile: esc = dequantisation x out_scale)
+          const float rdeq = 1.f / deq;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) xv[q] *= esc[q] * rdeq;
+        }
       }
+      if (dot_mode && AUXS) store8x(AUXS + off, xv, stream_out);  // aux * out_scale: the modulated input x * s
 #pragma unroll
       for (int q = 0; q < 8; ++q) o[q] += ebias[q];
       if (d.stats && !dot_mode) {

@@ -521,15 +521,22 @@ __global__ __launch_bounds__(NT) void resample_tile_kernel(const T* __restrict__
   const int ox0 = tx_ * OW, oy0 = blockIdx.y * OH, b = blockIdx.z;
   const int y_start = sy[oy0], x_start = sx[ox0];
   // vertical weights of the OH output rows on the PH patch rows (block-uniform -> scalar registers)
+  // (unconditional loads + selects: as `cond ? wy[...] : 0` every entry became its own scalar load behind its own
+  // branch and wait -- ~45 dependent scalar-cache round trips, ~25 us of prologue per block)
   float cy[OH][PH];
 #pragma unroll
   for (int o = 0; o < OH; ++o) {
     const int oy = min(oy0 + o, Ho - 1);
     const int off = sy[oy] - y_start;  // 0 .. SY * o
+    float wrow[TY];
+#pragma unroll
+    for (int t = 0; t < TY; ++t) wrow[t] = wy[oy * TY + t];
 #pragma unroll
     for (int k = 0; k < PH; ++k) {
-      const int t = k - off;
-      cy[o][k] = (t >= 0 && t < TY) ? wy[oy * TY + t] : 0.f;
+      float c = 0.f;
+#pragma unroll
+      for (int t = 0; t < TY; ++t) c = (k - off == t) ? wrow[t] : c;
+      cy[o][k] = c;
     }
   }
   const T* base = x + ((size_t)b * H * W) * C + (size_t)chunk * CVB * 8;

@@ -91,9 +91,10 @@ inline void done(int err, const char* op, bool meta) {
 
 void conv2d_fwd(const Tensor& x, const Tensor& w, Tensor& y, const OptT& in_scale, const OptT& out_scale,
                 const OptT& bias, const OptT& residual, int64_t pad, int64_t pad_mode, int64_t act,
-                bool per_sample_w, int64_t stride, const std::optional<Tensor>& stats, const OptT& deq, const OptT& aux) {
+                bool per_sample_w, int64_t stride, const std::optional<Tensor>& stats, const OptT& deq, const OptT& aux,
+                const std::optional<Tensor>& aux_scaled) {
   const char* op = "o2m::conv2d_fwd";
-  chk_f32(stats, op, "stats"); chk_f32(deq, op, "deq"); chk(aux, op, "aux");
+  chk_f32(stats, op, "stats"); chk_f32(deq, op, "deq"); chk(aux, op, "aux"); chk(aux_scaled, op, "aux_scaled");
   const bool f8 = is_fp8(x);
   chk(x, op, "x"); chk(w, op, "w"); chk(y, op, "y"); chk(residual, op, "residual");
   chk_f32(in_scale, op, "in_scale"); chk_f32(out_scale, op, "out_scale"); chk_f32(bias, op, "bias");
@@ -141,6 +142,13 @@ void conv2d_fwd(const Tensor& x, const Tensor& w, Tensor& y, const OptT& in_scal
     TORCH_CHECK(aux->sizes() == y.sizes() && aux->scalar_type() == y.scalar_type(), op, ": aux must have y's shape and dtype");
     d.aux = ptr(aux);
     d.stats_mode = O2M_STATS_DOT;
+    if (aux_scaled.has_value()) {
+      TORCH_CHECK(aux_scaled->sizes() == y.sizes() && aux_scaled->scalar_type() == y.scalar_type() && out_scale.has_value(), op,
+                  ": aux_scaled must have y's shape and dtype and needs out_scale");
+      d.aux_scaled = ptr(aux_scaled);
+    }
+  } else {
+    TORCH_CHECK(!aux_scaled.has_value(), op, ": aux_scaled needs aux");
   }
   O2M_CALL(op, x, o2m_conv2d_fwd(&d, stream));
 }
@@ -538,7 +546,8 @@ TORCH_LIBRARY(o2m, m) {
   m.def("instnorm_ws_floats(int B, int P, int C) -> int", &instnorm_ws_floats);
   m.def("reduce_blocks(int n) -> int", &reduce_blocks);
   m.def("conv2d_fwd(Tensor x, Tensor w, Tensor(a!) y, Tensor? in_scale, Tensor? out_scale, Tensor? bias, Tensor? residual, "
-        "int pad, int pad_mode, int act, bool per_sample_w, int stride, Tensor(b!)? stats=None, Tensor? deq=None, Tensor? aux=None) -> ()");
+        "int pad, int pad_mode, int act, bool per_sample_w, int stride, Tensor(b!)? stats=None, Tensor? deq=None, Tensor? aux=None, "
+        "Tensor(c!)? aux_scaled=None) -> ()");
   m.def("conv2d_dots_finalize(Tensor partial, Tensor(a!) dots, int nchunks) -> ()");
   m.def("amax(Tensor x, Tensor(a!) amax) -> ()");
   m.def("quantize_fp8(Tensor x, Tensor amax, Tensor(a!) y, Tensor(b!) deq) -> ()");

@@ -469,10 +469,11 @@ def _pad_cols(t: torch.Tensor, n: int) -> torch.Tensor:
 # ---------------------------------------------------------------------------------- conv
 
 
-# O2M_WGRAD_XS=1: the modulated input x * s for the weight gradient as a stored by-product of fold_scale_dot (the
-# round-2 form) instead of the weight-gradient kernel scaling x on its way into LDS (in_scale): one tensor write on
-# the main stream against a few more VALU instructions per staged vector on the weight-gradient stream.
-_WGRAD_XS = _os.environ.get("O2M_WGRAD_XS", "0") == "1"
+# The weight gradient of a modulated conv reduces gu x (x * s).  Default: x * s is a stored by-product of the pass
+# that reads x anyway (fold_scale_dot / the data-gradient epilogue).  O2M_WGRAD_INSCALE=1: the weight-gradient
+# kernel scales x while staging it instead (no tensor write; measured: +35 % kernel time and 16 more VGPRs, which
+# keep small kernels of the main stream from sharing its CUs -- kept for A/B).
+_WGRAD_XS = _os.environ.get("O2M_WGRAD_INSCALE", "0") != "1"
 # O2M_FUSED_DGRAD_DOT=0: zero-padded modulated convs run fold_scale_dot behind their data gradient (round-2 form)
 # instead of taking the style scale and the style dot out of the data-gradient epilogue (O2M_STATS_DOT)
 _FUSED_DGRAD_DOT = _os.environ.get("O2M_FUSED_DGRAD_DOT", "1") == "1"
@@ -646,7 +647,7 @@ class _ConvFn(torch.autograd.Function):
             # + THIS conv's activation backward and sums in one pass over (padded gradient, u)
             gu = torch.empty_like(g)
             H.fold_scale_dot(deferred["gxp"], y, deferred["s"], gu, deferred["dots"], deferred["pad"],
-                             act=act, act_mul=d, act_sums=sums)
+                             xs=deferred["xs"], act=act, act_mul=d, act_sums=sums)
             deferred["finish"]()
         elif act != H.ACT_NONE or d is not None:
             gu = torch.empty_like(g)
@@ -675,6 +676,22 @@ class _ConvFn(torch.autograd.Function):
         if tail and g_res is not None and need_x:
             link.res_grad, g_res = g_res, None  # the block's first conv adds it to its data gradient
 
+        # to_style gradients: a decoder layer is applied five times per generator step; when the parameters
+        # already own fp32 .grad buffers (FusedAdam's flat bucket) the kernel adds straight into them instead of
+        # autograd summing temporaries per parameter
+        direct = make_direct = False
+        if run_style:
+            tsw, tsb = ctx.ts_params
+
+            def grad_ok(p):
+                return p.grad.dtype == torch.float32 and p.grad.is_contiguous() and p.grad.device == dev
+
+            wanted = all(ctx.needs_input_grad[k] and p is not None for k, p in ((4, tsw), (5, tsb)))
+            direct = _DIRECT_STYLE_GRADS and wanted and all(p.grad is not None and grad_ok(p) for p in (tsw, tsb))
+            # a deferred style backward (below) fills its outputs AFTER this function has returned them: only the
+            # in-place route into .grad is safe then (autograd would accumulate the returned temporaries at once)
+            make_direct = wanted and all(p.grad is None or grad_ok(p) for p in (tsw, tsb))
+
         g_x = xs = None
         defer_fold = False
         if need_x or need_s:
@@ -682,8 +699,10 @@ class _ConvFn(torch.autograd.Function):
                 nchunks = hp * wp // dot_rows
                 part = torch.empty(B * nchunks * cip * 2, dtype=torch.float32, device=dev)
                 g_x = torch.empty_like(x)
+                if need_w and _WGRAD_XS:
+                    xs = torch.empty_like(x)  # x * s for the weight gradient, written while x is in registers
                 H.conv2d_fwd(gu, w_d, g_x, out_scale=s, pad=kpad, pad_mode=H.PAD_ZERO, act=H.ACT_NONE,
-                             stats=part, aux=x)
+                             stats=part, aux=x, aux_scaled=xs)
                 dots = torch.empty((B, cip), dtype=torch.float32, device=dev)
                 H.conv2d_dots_finalize(part, dots, nchunks)
             else:
@@ -698,10 +717,17 @@ class _ConvFn(torch.autograd.Function):
                     # the block's first conv finishes this (BlockLink.deferred) when it can fuse its activation
                     # backward: its output is this conv's input, and nothing else wants dL/dx
                     defer_fold = (tail and link.fuse_act and s is not None and need_x
-                                  and not (_WGRAD_XS and need_w))
+                                  and (not run_style or direct or make_direct))
+                    if defer_fold and run_style and not direct:
+                        for p in (tsw, tsb):
+                            if p.grad is None:
+                                p.grad = torch.zeros_like(p, dtype=torch.float32)
+                        direct = True
                     if defer_fold:
                         g_x = torch.empty_like(x)  # never read: the head checks that it gets exactly this back
                         link.lazy_ptr = g_x.data_ptr()
+                        if need_w and _WGRAD_XS:
+                            xs = torch.empty_like(x)  # written by the head's fused kernel
                     else:
                         g_x = torch.empty_like(x)
                         if s is not None and need_w and _WGRAD_XS:
@@ -721,13 +747,6 @@ class _ConvFn(torch.autograd.Function):
             e = torch.empty((B, prep.cop), dtype=torch.float32, device=dev) if d is not None else None
             gs = torch.empty((B, cip), dtype=torch.float32, device=dev)
             g_ws = torch.empty((B, wd_), dtype=torch.float32, device=dev)
-            # to_style gradients: a decoder layer is applied five times per generator step; when the
-            # parameters already own fp32 .grad buffers (FusedAdam's flat bucket) the kernel adds
-            # straight into them instead of autograd summing five temporaries per parameter
-            tsw, tsb = ctx.ts_params
-            direct = _DIRECT_STYLE_GRADS and all(
-                ctx.needs_input_grad[k] and p is not None and p.grad is not None and p.grad.dtype == torch.float32
-                and p.grad.is_contiguous() and p.grad.device == dev for k, p in ((4, tsw), (5, tsb)))
             if direct:
                 g_tw, g_tb = tsw.grad, tsb.grad
                 prep.direct_style = (tsw, tsb)  # reported complete together with the filter (_finalize_layer)
@@ -742,11 +761,13 @@ class _ConvFn(torch.autograd.Function):
                 ev_pre.record(torch.cuda.current_stream(dev))
 
         # ---- 3. weight gradient (own stream) ---------------------------------------------------------------
-        gq_acc = None
+        gq_acc = dw_acc = None
         if need_w:
             # accumulated in the kernel layout across every use of the layer in this backward;
             # converted into weight.grad once, by _finalize_weight_grads
             dw_acc, gq_acc = prep.accumulators(dev)
+
+        def launch_wgrad():
             wst = _wgrad_stream(dev)
             if wst is not None:
                 ev_w = torch.cuda.Event()
@@ -762,6 +783,9 @@ class _ConvFn(torch.autograd.Function):
                     H.conv2d_wgrad(xs, gu, dw_acc, pad=pad, pad_mode=pad_mode)
                 else:  # plain conv (s None), or the modulated input formed while x is staged (in_scale)
                     H.conv2d_wgrad(x, gu, dw_acc, in_scale=s, pad=pad, pad_mode=pad_mode)
+
+        if need_w and not defer_fold:
+            launch_wgrad()
 
         # ---- 4. style path (B x C sized) -------------------------------------------------------------------
         def style_and_count():
@@ -787,16 +811,18 @@ class _ConvFn(torch.autograd.Function):
             # dots is written by the head's fused kernel; the style backward reads it: both run from there.
             # (g_ws is allocated now and filled then -- before anything downstream of this backward can read it:
             # the head's backward runs earlier in stream order than any consumer of the style gradients.)
+            def finish():
+                if need_w:
+                    launch_wgrad()  # x * s has just been written by the head's fused kernel
+                style_and_count()
+
             link.deferred = {"gxp": gxp, "s": s, "dots": dots, "pad": pad if pad_mode == H.PAD_REFLECT else 0,
-                             "finish": style_and_count}
+                             "xs": xs, "finish": finish}
         else:
             style_and_count()
-        if run_style:
-            if direct:
-                g_tw = g_tb = None  # already in .grad
-        else:
-            g_ws = g_tw = g_tb = None
-        return (g_x if need_x else None, None, g_bias, g_ws, g_tw, g_tb, g_res,
+        # (separate names: style_and_count may run later, from the block's first conv, and reads g_tw / g_tb)
+        r_ws, r_tw, r_tb = (g_ws, None if direct else g_tw, None if direct else g_tb) if run_style else (None,) * 3
+        return (g_x if need_x else None, None, g_bias, r_ws, r_tw, r_tb, g_res,
                 None, None, None, None, None, None, None, None)
 
 

@@ -592,10 +592,12 @@ def test_data_gradient_epilogue_emits_style_scale_and_dot(shape):
     assert rows > 0 and (Hh * Ww) % rows == 0
     nchunks = Hh * Ww // rows
     part = torch.full((B * nchunks * Cn * 2,), float("nan"), device="cuda")
-    gx1, dots1 = torch.empty_like(x), torch.empty(B, Cn, device="cuda")
-    H.conv2d_fwd(gu, w_d, gx1, out_scale=s, pad=1, pad_mode=H.PAD_ZERO, act=H.ACT_NONE, stats=part, aux=x)
+    gx1, dots1, xs1 = torch.empty_like(x), torch.empty(B, Cn, device="cuda"), torch.empty_like(x)
+    H.conv2d_fwd(gu, w_d, gx1, out_scale=s, pad=1, pad_mode=H.PAD_ZERO, act=H.ACT_NONE, stats=part, aux=x,
+                 aux_scaled=xs1)
     H.conv2d_dots_finalize(part, dots1, nchunks)
     torch.cuda.synchronize()
+    assert torch.equal(xs1, (x.float() * s[:, None, None, :]).bfloat16()), "aux_scaled = the modulated input x * s"
     # gx0 went through a bf16 rounding of the unscaled gradient first: one bf16 ulp of slack
     assert float((gx1.double() - gx0.double()).norm() / gx0.double().norm()) < 6e-3
     # the fused dot uses the fp32 accumulator, the separate one the rounded gradient
