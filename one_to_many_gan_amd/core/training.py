@@ -162,6 +162,23 @@ def _batched_decodes(config, device, generator, discriminator, mapping_network, 
     d1, d2 = (theta + h / 2).clamp(0, 1), (theta - h / 2).clamp(0, 1)
     w1, w2 = mapping_network.get_two_w(batch, blocks, device, (d1, d2))
 
+    # The extraction group depends on the latents and the style vectors only: it runs on a second stream, so its
+    # HBM-bound kernels share the chip with the decode group's MFMA kernels (and the reverse) in forward AND in
+    # backward (autograd runs a node's backward on the stream of its forward and orders the streams itself).
+    side = ops.group_stream(device)
+    w_ext = torch.cat([w1, w2], dim=1)
+
+    def extraction_group():
+        feats = generator._decode(ops.batch_gather(t_lat, batch, (0, 0)), w_ext, collect=True, internal=True)
+        return path_loss_halves(feats, h)
+
+    if side is not None:
+        main = torch.cuda.current_stream(device)
+        generator.prepare_decoder_weights()  # both groups read the cached filter forms: build them before the fork
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            path = extraction_group()
+
     w_dec = torch.cat([w_zero, w_mark.expand(blocks, *w_mark.shape), w_trans], dim=1)
     images = generator._decode(ops.batch_gather(t_lat, batch, (0, 1, 0)), w_dec, collect=False, internal=True)
     rec_t, idt_t, gen_t = ops.split_batch(images, 3)
@@ -174,9 +191,11 @@ def _batched_decodes(config, device, generator, discriminator, mapping_network, 
 
     style = style_cycle_loss_func(w_trans[-1], style_extractor(generated))
 
-    feats = generator._decode(ops.batch_gather(t_lat, batch, (0, 0)), torch.cat([w1, w2], dim=1),
-                              collect=True, internal=True)
-    path = path_loss_halves(feats, h)
+    if side is None:
+        path = extraction_group()
+    else:
+        main.wait_stream(side)
+        path.record_stream(main)
     return rec, idt, gan, style, path
 
 

@@ -133,10 +133,12 @@ __global__ __launch_bounds__(NT) void style_bwd_batch_kernel(const float* gs, co
       sb += g;
       for (int j = 0; j < WD; ++j) acc[j] += g * w[(size_t)b * WD + j];
     }
-    // one writer per element: accumulate = 1 adds into the caller's buffers (the parameters' .grad)
+    // accumulate = 1 adds into the caller's buffers (the parameters' .grad).  One writer per element WITHIN a
+    // launch; fp32 atomics because two launches for the same layer may run at the same time on two streams (the
+    // decode and the extraction group of generator_step, core/training.py)
     if (accumulate) {
-      gbs[i] += sb;
-      for (int j = 0; j < WD; ++j) gWs[(size_t)i * WD + j] += acc[j] * cs;
+      atomicAdd(gbs + i, sb);
+      for (int j = 0; j < WD; ++j) atomicAdd(gWs + (size_t)i * WD + j, acc[j] * cs);
     } else {
       gbs[i] = sb;
       for (int j = 0; j < WD; ++j) gWs[(size_t)i * WD + j] = acc[j] * cs;
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(NT) void style_bwd_batch_kernel(const float* gs, co
       const float sv = s[(size_t)b * Cip + i];
       a += e[(size_t)b * Cop + o] * sv * sv;
     }
-    gq[(size_t)o * Cip + i] += a;  // accumulates over the uses of the layer in one backward
+    atomicAdd(gq + (size_t)o * Cip + i, a);  // accumulates over the uses of the layer in one backward (see above)
   }
 }
 

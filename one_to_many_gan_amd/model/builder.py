@@ -143,6 +143,13 @@ class Generator(nn.Module):
                     return feats
         raise ValueError("No return layers specified.")
 
+    def prepare_decoder_weights(self):
+        """Kernel-side forms of every decoder filter, on the CURRENT stream (before a step forks a second
+        stream that uses them too; a no-op when they are cached for the current parameter version)."""
+        for m in self.decoder.modules():
+            if isinstance(m, (EqualisedConv2d, Conv2dWeightModulate)):
+                m._prepared().get()
+
     # ---- reference API -----------------------------------------------------------------------
     def encode(self, x: torch.Tensor):
         """Encode x to latent space z."""

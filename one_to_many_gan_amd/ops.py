@@ -349,6 +349,23 @@ def _wgrad_stream(device):
     return st
 
 
+# O2M_GROUP_STREAM=0: generator_step's extraction group on the main stream (default: its own stream, so that its
+# HBM-bound kernels run beside the decode group's MFMA kernels and vice versa; off in deterministic mode -- two
+# concurrent style backward launches of one layer add into the same accumulators)
+_GROUP_STREAM = _os.environ.get("O2M_GROUP_STREAM", "1") == "1"
+_GSTREAM: dict = {}
+
+
+def group_stream(device):
+    """Second compute stream for an independent sub-graph of a step (None: run it on the current stream)."""
+    if not _GROUP_STREAM or device.type != "cuda" or deterministic():
+        return None
+    st = _GSTREAM.get(device)
+    if st is None:
+        st = _GSTREAM[device] = torch.cuda.Stream(device=device)
+    return st
+
+
 def _side_stream(device):
     if not _SIDE_STREAM or device.type != "cuda":
         return None
@@ -418,6 +435,8 @@ def _finalize_weight_grads():
     _PASS["task"] = None
     for dev, wst in _WSTREAM.items():  # weight gradients reduced on their own stream
         torch.cuda.current_stream(dev).wait_stream(wst)
+    for dev, gst in _GSTREAM.items():  # style gradients accumulated by a group that ran on its own stream
+        torch.cuda.current_stream(dev).wait_stream(gst)
     for prep in pend:
         if prep.pending:
             _finalize_layer(prep)
