@@ -1094,6 +1094,248 @@ int launch_p8(const o2m_conv_desc& d, hipStream_t s, long m_begin, long m_end) {
   return 0;
 }
 
+// =============================================================================================
+// Halo-tile kernel ("h3") for the NARROW 3 x 3 layers at large maps: zero padding 1, stride 1, bf16,
+// Ci % 64 == 0, Co = 64 or 128, W % 32 == 0, H % 8 == 0 (the 64 <-> 128-channel layers at 256 x 256 / 128 x 128
+// and their data gradients).  The implicit-GEMM tiles above fetch the A operand once PER TAP: nine L2 -> LDS
+// trips per input element, 52 FLOP per ingested byte at N = 64 -- they sit on the L2 -> LDS ingest limit
+// (~60 GB/s per CU) at 0.2 of the MFMA peak (profiles/r02_c_pmc_igemm_256x64.json).  Here a block owns an
+// 8 x 32 tile of output pixels of ONE sample and keeps the 10 x 34 input patch of a 64-channel chunk resident
+// in LDS (43 KB): all nine taps read their A fragments from it at shifted pixel offsets, so an input element
+// is ingested once per chunk (plus the 1.33x halo), 3.4x less than before; only the filter taps (8 / 16 KB
+// each) stream, double-buffered, one tap ahead.
+//  * 8 waves = 4 (M: two image rows of the tile each) x 2 (N), v_mfma_f32_16x16x32_bf16, 32 / 64 accumulator
+//    registers: TWO blocks per CU (60 / 77 KB of LDS each), which is what hides a block's patch load and
+//    epilogue -- no phase choreography needed.
+//  * patch image: pixel pp = py * 34 + px at byte pp * 128, 16-B chunk c at slot c ^ ((pp >> 1) & 7): 16
+//    consecutive pixels (one fragment read, at ANY tap shift) cover all 16 slots of their bank rows.  Filled by
+//    LDS-DMA with the swizzle on the source side; out-of-image pixels (the zero padding) are out-of-range
+//    offsets, i.e. hardware zero fill.
+// Epilogue as in conv_igemm_kernel (fp32 tile through LDS, whole channel vectors out; demodulation, bias,
+// activation, residual, InstanceNorm / style-dot partials), one wave row = 64 pixels = two image-row segments
+// per pass.
+// =============================================================================================
+template <int CO>
+__global__ __launch_bounds__(512, 4) void conv3x3_halo_kernel(const o2m_conv_desc d) {
+  using T = unsigned short;
+  constexpr int NT = 512, TH = 8, TW = 32, PW = TW + 2, NPIX = (TH + 2) * PW;  // 340 patch pixels
+  constexpr int PFILLS = (NPIX + 7) / 8;                                       // 43 fills of 8 pixels
+  constexpr int PATCH_B = PFILLS * 1024;
+  constexpr int WB = CO * 128;     // one filter tap of one chunk: CO rows x 64 channels
+  constexpr int WFILLS = CO / 8;   // 8 rows per fill
+  constexpr int WPW = WFILLS / 8;  // filter fills per wave (1 or 2)
+  constexpr int NJ = CO / 32;      // 16-column MFMA tiles per wave (wave N = CO / 2)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* patch = smem;
+  char* wbuf = smem + PATCH_B;
+  typedef __attribute__((address_space(3))) void lds_void;
+
+  const int H = d.H, W = d.W, Ci = d.Ci, Co = d.Co;
+  const int K = 9 * Ci;
+  const int tiles_x = W / TW, tiles_y = H / TH, tps = tiles_x * tiles_y;
+  const int tile = xcd_tile_order(blockIdx.x, gridDim.x);
+  const int b = tile / tps, tis = tile - b * tps;
+  const int ty0 = (tis / tiles_x) * TH, tx0 = (tis % tiles_x) * TW;
+  const rsrc_t xr = make_rsrc(d.x, (unsigned)((size_t)d.B * H * W * Ci * 2));
+  const rsrc_t wr = make_rsrc(static_cast<const char*>(d.w) + (size_t)b * d.w_batch_stride * 2, (unsigned)((size_t)Co * K * 2));
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // ---- patch fills: fill f = 8 j + wave covers patch pixels 8 f .. 8 f + 7; lane l owns slot (l & 7) of pixel
+  // 8 f + (l >> 3).  The six source offsets are recomputed per chunk (once or twice per block) rather than kept
+  // in registers across the tap loop: the kernel must fit 128 VGPRs for two blocks per CU.
+  auto issue_patch = [&](int cb) {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));  // keeps the offset arithmetic below inside the chunk loop
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int f = 8 * j + wave;
+      if (f >= PFILLS) continue;  // wave-uniform
+      const int pp = 8 * f + (ln >> 3);
+      const int c = (ln & 7) ^ ((pp >> 1) & 7);
+      const int py = pp / PW, px = pp - py * PW;
+      const int gy = ty0 + py - 1, gx = tx0 + px - 1;
+      const bool ok = pp < NPIX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      const unsigned off = ok ? (unsigned)(((b * H + gy) * W + gx) * Ci + c * 8) * 2u : OOB_OFF;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void*)(patch + f * 1024), 16, (int)off, cb * 2, 0, 0);
+    }
+  };
+  // ---- filter fills: tile_off's swizzle, lane l of the fill of 8-row group q owns linear slot 64 q + l
+  unsigned woff[WPW];
+#pragma unroll
+  for (int j = 0; j < WPW; ++j) {
+    const int q = WPW * wave + j;
+    const int pr = 4 * q + (lane >> 4);
+    const int row = 2 * pr + (((lane & 15) ^ (pr & 15)) >> 3), chk = ((lane & 15) ^ (pr & 15)) & 7;
+    woff[j] = (unsigned)(row * K + chk * 8) * 2u;
+  }
+  auto issue_w = [&](int tap, int cb, int buf) {
+#pragma unroll
+    for (int j = 0; j < WPW; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void*)(wbuf + buf * WB + (WPW * wave + j) * 1024), 16, (int)woff[j],
+                                               (tap * Ci + cb) * 2, 0, 0);
+  };
+
+  // ---- fragments -------------------------------------------------------------------------------------
+  // A: lane l holds pixel row (l & 15) of a 16-row tile and reduction elements 8 (l >> 4) + 32 ks .. + 7
+  const int c0 = lane >> 4;
+  // patch pixel of this lane's row at tap (0, 0) in 16-row tile 0; tile i adds (i >> 1) image rows and 16 (i & 1) pixels
+  const int ppb0 = 2 * wm * PW + (lane & 15);
+  // tile_off(R0 + 16 j + r, c) = (tile_off(R0 + r, c) ^ ((j & 1) << 7)) + j * 2048 for R0 % 32 == 0 (as in the p8 kernel)
+  const int fb0 = tile_off(wn * (CO / 2) + (lane & 15), c0);
+
+  f32x4_t acc[4][NJ];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](const int toff, const int buf) {
+    int aoff[4];
+    int pb = ppb0;
+    asm volatile("" : "+v"(pb));  // recompute the four offsets per tap: hoisted, the 36 of them spill to scratch
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int pp = pb + (toff + (i >> 1) * PW + (i & 1) * 16);
+      aoff[i] = (pp << 7) | ((c0 ^ ((pp >> 1) & 7)) << 4);
+    }
+    const char* wb = wbuf + buf * WB;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 a[4], bw[NJ];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8*>(patch + (aoff[i] ^ (ks << 6)));
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) bw[j] = *reinterpret_cast<const bf16x8*>(wb + ((fb0 ^ (((j & 1) << 7) | (ks << 6))) + j * 2048));
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bw[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  // ---- main loop: per 64-channel chunk, the patch once and the nine taps from it ------------------------
+  for (int cb = 0; cb < Ci; cb += 64) {
+    issue_patch(cb);
+    issue_w(0, cb, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      if (tap < 8) issue_w(tap + 1, cb, (tap + 1) & 1);  // lands while this tap is multiplied
+      compute((tap / 3) * PW + tap % 3, tap & 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();  // next tap's filter has landed; every wave is done with this tap's (and, at tap 8, the patch)
+    }
+  }
+
+  // ---- epilogue -----------------------------------------------------------------------------------------
+  constexpr int CSTR = CO + 4;
+  constexpr int VPR = CO / 8, RPI = NT / VPR;  // 8-channel vectors per row; rows per read-out iteration
+  float* csm = reinterpret_cast<float*>(smem);
+  T* __restrict__ Y = static_cast<T*>(d.y);
+  const T* __restrict__ R = static_cast<const T*>(d.residual);
+  const T* __restrict__ AUX = static_cast<const T*>(d.aux);
+  T* __restrict__ AUXS = static_cast<T*>(d.aux_scaled);
+  const int act = d.act;
+  const bool dot_mode = d.stats && d.stats_mode == O2M_STATS_DOT;
+  const bool stream_out = (size_t)d.B * H * W * Co * 2 >= ((size_t)64 << 20);
+  const int ec8 = tid % VPR, erow = tid / VPR, en = ec8 * 8;
+  float esc[8], ebias[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { esc[q] = 1.f; ebias[q] = 0.f; }
+  if (d.out_scale) {
+    const float* sp = d.out_scale + (size_t)b * Co + en;
+    const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 4);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { esc[q] = s0[q]; esc[4 + q] = s1[q]; }
+  }
+  if (d.bias) {
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(d.bias + en), b1 = *reinterpret_cast<const f32x4*>(d.bias + en + 4);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { ebias[q] = b0[q]; ebias[4 + q] = b1[q]; }
+  }
+#pragma unroll 1
+  for (int pass = 0; pass < 4; ++pass) {  // wave row `pass`: tile image rows 2 pass, 2 pass + 1
+    if (wm == pass) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            csm[(i * 16 + 4 * (lane >> 4) + r) * CSTR + wn * (CO / 2) + j * 16 + (lane & 15)] = acc[i][j][r];
+    }
+    lds_barrier();
+    float st[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) st[q] = 0.f;
+#pragma unroll
+    for (int it = 0; it < 64 / RPI; ++it) {
+      const int row = erow + it * RPI;  // 0 .. 63
+      const int gy = ty0 + 2 * pass + (row >> 5), gx = tx0 + (row & 31);
+      const size_t off = ((size_t)(b * H + gy) * W + gx) * Co + en;
+      const f32x4 va = *reinterpret_cast<const f32x4*>(csm + row * CSTR + ec8 * 8);
+      const f32x4 vb = *reinterpret_cast<const f32x4*>(csm + row * CSTR + ec8 * 8 + 4);
+      float o[8] = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
+      if (dot_mode) {
+        float xv[8];
+        load8x(AUX + off, xv, stream_out);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) st[q] += o[q] * xv[q];
+        if (AUXS) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) xv[q] *= esc[q];
+          store8x(AUXS + off, xv, stream_out);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) o[q] = o[q] * esc[q] + ebias[q];
+      if (d.stats && !dot_mode) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { st[q] += o[q]; st[8 + q] += o[q] * o[q]; }
+      }
+      act_fwd8(o, act);
+      if (R) {
+        float rv[8];
+        load8(R + off, rv);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] += rv[q];
+      }
+      store8x(Y + off, o, stream_out);
+    }
+    // one partial per (tile, wave row): 64 pixels of the sample; o2m_instnorm_finalize / o2m_conv2d_dots_finalize
+    // add a sample's H W / 64 partials whatever pixels each covers
+    if (d.stats) stats_block_reduce<NT, VPR>(st, csm, d.stats, ((long)b * tps + tis) * 4 + pass, 0, Co, tid);
+    lds_barrier();
+  }
+}
+
+template <int CO>
+int launch_halo(const o2m_conv_desc& d, hipStream_t s) {
+  constexpr int lds_main = 43 * 1024 + 2 * CO * 128, lds_epi = 64 * (CO + 4) * 4, lds_red = 16 * 512 * 4;
+  constexpr int lds = lds_main > lds_epi ? (lds_main > lds_red ? lds_main : lds_red) : (lds_epi > lds_red ? lds_epi : lds_red);
+  const long tiles = (long)d.B * (d.H / 8) * (d.W / 32);
+  if (tiles <= 0 || tiles > 0x7fffffffL) return O2M_ERR_BAD_ARG;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<CO>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  {
+    LaunchScope timed(s, 2.0 * d.B * d.H * d.W * d.Co * 9.0 * d.Ci, "conv3x3_halo<bf16,8x32x%d>", CO);
+    hipLaunchKernelGGL(conv3x3_halo_kernel<CO>, dim3((unsigned)tiles), dim3(512), lds, s, d);
+  }
+  O2M_LAUNCH_CHECK();
+  return 0;
+}
+
+// the layers the halo-tile kernel takes (host side of its preconditions)
+inline bool halo_ok(const o2m_conv_desc& d) {
+  static const int on = [] { const char* e = getenv("O2M_CONV_HALO"); return e ? atoi(e) : 1; }();
+  return on && d.dtype == O2M_BF16 && d.KH == 3 && d.KW == 3 && d.pad == 1 && d.pad_mode == O2M_PAD_ZERO && d.stride <= 1 &&
+         !d.in_scale && d.Ci % 64 == 0 && (d.Co == 64 || d.Co == 128) && d.W % 32 == 0 && d.H % 8 == 0 &&
+         (long)d.B * (d.H / 8) * (d.W / 32) >= 2 * kFillBlocks;
+}
+
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
 int launch_cfg(const o2m_conv_desc& d, hipStream_t s, long m_begin = 0, long m_end = -1) {
   constexpr int NT = 64 * WAVES_M * WAVES_N;
@@ -1123,6 +1365,9 @@ int launch_cfg(const o2m_conv_desc& d, hipStream_t s, long m_begin = 0, long m_e
 
 template <typename T>
 int launch_dtype(const o2m_conv_desc& d, hipStream_t s) {
+  if constexpr (sizeof(T) == 2) {
+    if (halo_ok(d)) return d.Co == 64 ? launch_halo<64>(d, s) : launch_halo<128>(d, s);
+  }
   // big 8-wave tiles when they still give every CU a block; otherwise the 4-wave 128-wide
   // tiles (small-M layers of the discriminator) so the chip stays filled
   if (d.Co > 128) {
@@ -1172,6 +1417,7 @@ int launch_dtype(const o2m_conv_desc& d, hipStream_t s) {
 // (mirrors launch_dtype below)
 static int stats_rows_for(const o2m_conv_desc& d) {
   if (d.stride > 1 || d.in_scale) return 0;
+  if (d.dtype == O2M_BF16 && halo_ok(d)) return 64;  // one partial per wave row of an 8 x 32 tile
   if (d.Co > 128) {
     if (tiles_for<256, 256>(d) >= kFillBlocks) return 128;  // p8 and the symmetric 256x256 kernel alike
     return 64;                                               // 128x128, 2x2 waves

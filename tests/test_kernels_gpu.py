@@ -201,6 +201,10 @@ FULL_SIZE_CONVS = [
     (16, 128, 128, 128, 256, 3, 1, False, "epilogue"),  # Ci = 128: a tap is two K-tiles
     (16, 256, 256, 128, 64, 3, 1, False, "epilogue"),  # N = 64 tile
     (16, 128, 128, 256, 128, 3, 1, False, "modulated"),  # N = 128 tile, modulated
+    # round 3: the halo-tile kernel (zero pad 1, Co = 64 / 128, W % 32 == 0, >= 512 tiles) in each of its forms
+    (16, 256, 256, 64, 128, 3, 1, False, "plain"),       # Co = 128, one 64-channel chunk
+    (4, 256, 256, 128, 64, 3, 1, False, "modulated"),    # Co = 64, two chunks, per-sample filters + demodulation
+    (2, 256, 256, 64, 64, 3, 1, False, "epilogue"),      # the minimum grid (512 tiles), bias + act + residual
 ]
 
 
@@ -571,8 +575,9 @@ def test_fold_scale_dot_residual_and_fused_activation_match_the_separate_kernels
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("shape", [(2, 32, 32, 64, 128), (4, 128, 128, 64, 256), (3, 64, 64, 128, 64)],
-                         ids=["256x64-tile", "p8", "co64"])
+@pytest.mark.parametrize("shape", [(2, 32, 32, 64, 128), (4, 128, 128, 64, 256), (3, 64, 64, 128, 64),
+                                   (2, 256, 256, 64, 128), (8, 128, 128, 128, 64)],
+                         ids=["256x64-tile", "p8", "co64", "halo128", "halo64"])
 def test_data_gradient_epilogue_emits_style_scale_and_dot(shape):
     """O2M_STATS_DOT: the data gradient of a zero-padded modulated conv leaves the GEMM epilogue multiplied by the
     style and with its style dot as row-block partials -- against conv + o2m_fold_scale_dot(pad 0)."""
@@ -647,3 +652,32 @@ def test_transposed_upsample_tile_kernel_matches_the_dense_operator(dt):
         ref = torch.einsum("ip,bpqc,jq->bijc", a_h, g.double().cpu(), a_w)
         err = float((out.double().cpu() - ref).norm() / ref.norm())
         assert err < (1e-6 if dt == torch.float32 else 4e-3), (B, n_h, n_w, C, err)
+
+
+@pytest.mark.parametrize("co", [64, 128])
+def test_halo_kernel_instance_norm_partials_match_the_statistics_pass(co):
+    """The halo-tile kernel's InstanceNorm partials (one per wave row of an 8 x 32 tile: NOT consecutive pixels)
+    through o2m_instnorm_finalize against the separate statistics pass over y."""
+    from one_to_many_gan_amd import _hip as H
+
+    torch.manual_seed(15)
+    B, S, Ci = 2, 256, 64
+    x = torch.randn(B, S, S, Ci, device="cuda").bfloat16()
+    w = (torch.randn(co, 3, 3, Ci, device="cuda") / (3 * Ci ** 0.5)).bfloat16()
+    bias = torch.randn(co, device="cuda")
+    y = torch.empty(B, S, S, co, device="cuda", dtype=torch.bfloat16)
+    rows = H.conv2d_stats_rows(x, w, y, pad=1)
+    assert rows == 64
+    nchunks = S * S // rows
+    part = torch.full((B * nchunks * co * 2,), float("nan"), device="cuda")
+    H.conv2d_fwd(x, w, y, bias=bias, pad=1, pad_mode=H.PAD_ZERO, act=H.ACT_NONE, stats=part)
+    mr = torch.empty(B, co, 2, device="cuda")
+    H.instnorm_finalize(part, mr, S * S, nchunks, 1e-5)
+    ws = torch.empty(H.instnorm_ws_floats(B, S * S, co), device="cuda")
+    mr0 = torch.empty(B, co, 2, device="cuda")
+    H.instnorm_stats(y, ws, mr0, 1e-5)
+    torch.cuda.synchronize()
+    assert torch.isfinite(mr).all()
+    # (the epilogue sums the fp32 accumulators, the pass the bf16-rounded y)
+    assert float((mr[..., 0] - mr0[..., 0]).abs().max()) < 2e-3
+    assert float(((mr[..., 1] - mr0[..., 1]) / mr0[..., 1]).abs().max()) < 2e-3
