@@ -379,6 +379,237 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(float* __restrict__ d
   reinterpret_cast<f32x4*>(dw)[i] = acc;
 }
 
+// =============================================================================================
+// Phase-pipelined weight gradient ("wgrad p8") for the 256 -> 256 3 x 3 layers on 64-pixel-wide maps (every
+// ResNet / modulated block of the generator: ~55 % of the step's weight-gradient time).  Same skeleton as
+// conv_igemm_p8_kernel -- 256 x 256 tile, 8 waves = 2 x 4, v_mfma_f32_16x16x32_bf16, four phases per K-tile, LDS-DMA
+// fills in four regions issued five phases ahead behind ONE counted vmcnt(8), the two wave rows one barrier apart --
+// with the GEMM turned on its side:
+//   C[co][kcol] += sum_px G[px][co] * X[px (+) tap][kcol],   rows = 256 output channels, columns = the 256 input
+//   channels of ONE filter tap (blockIdx -> tap), reduction = pixels, one image row (64 px) per K-tile.
+// Both operands sit in HBM with the REDUCTION index slow (NHWC), so the tiles are staged as they are ([64 px][256 B]
+// region images) and the fragments come out of LDS with ds_read_b64_tr_b16 (the CDNA4 transposing read): lane i of a
+// 16-lane group gets column i of 4 consecutive pixel rows, two reads = the 8 consecutive reduction elements the MFMA
+// wants.  The 16-B chunks of a row are XOR-swizzled (source side of the DMA) with ((row & 3) << 1 | (row >> 3 & 1) << 3)
+// so the eight pixel rows one half-wave read touches land in eight different 32-B bank windows.
+// Every lane's source offset is a constant of the block: a K-tile is one whole image row, so the pixel column, its
+// mirror / padding test for the tap's dx and the channel chunk never change; only the row base moves (an SGPR).
+// Output: the block's 256 x 256 fp32 tile goes to its slice's slab (o2m_wgrad_desc.slabs); wgrad_reduce_kernel adds
+// the slices in order as before (bitwise reproducible).
+// =============================================================================================
+__global__ __launch_bounds__(512, 2) void conv_wgrad_p8_kernel(const o2m_wgrad_desc d, const int rows_per_split) {
+  constexpr int REG = 16384;   // one region image: 64 pixel rows x 256 B
+  constexpr int BUFB = 65536;  // A0 | A1 | B0 | B1 of one K-tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) void lds_void;
+
+  const int H = d.H, W = d.W, Ci = d.Ci, Co = d.Co, pad = d.pad;
+  const int K = 9 * Ci;
+  const bool reflect = d.pad_mode == O2M_PAD_REFLECT;
+  const int bid = xcd_tile_order(blockIdx.x, gridDim.x);  // the nine taps of a slice share G and x: one XCD
+  const int tap = bid % 9, split = bid / 9;
+  const int dy = tap / 3 - pad, dx = tap % 3 - pad;
+  const int r_total = d.B * H;  // image rows = K-tiles of the whole problem
+  const int r_begin = split * rows_per_split;
+  const int nk = min(r_total, r_begin + rows_per_split) - r_begin;
+  if (nk <= 0) return;  // uniform
+  const rsrc_t xr = make_rsrc(d.x, (unsigned)((size_t)d.B * H * W * Ci * 2));
+  const rsrc_t gr = make_rsrc(d.gy, (unsigned)((size_t)d.B * H * W * Co * 2));
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int wrow = wave >> 2, wcol = wave & 3;
+
+  // ---- fills: region fill q (0..15) = pixel rows 4 q .. 4 q + 3; the wave owns fills 2 w, 2 w + 1 of every region.
+  // Lane l owns slot (l & 15) of row 4 q + (l >> 4) and fetches the chunk the swizzle maps there.
+  unsigned goff[2][2], xoff[2][2];  // [region half][fill of the wave]
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj) {
+    const int row = 4 * (2 * wave + jj) + (lane >> 4);
+    const int chunk = (lane & 15) ^ (((row & 3) << 1) | (((row >> 3) & 1) << 3));
+    // A regions: chunks 0-7 = channels 0-63 (+64 for A1) of wave row 0, chunks 8-15 = the same of wave row 1
+    const int co0 = (chunk >> 3) * 128 + (chunk & 7) * 8;
+    // B regions: chunk c = columns 64 (c >> 2) + 8 (c & 3) (+32 for B1): the first / second 32 columns of each wave column
+    const int kc0 = (chunk >> 2) * 64 + (chunk & 3) * 8;
+    int ix = row + dx;  // the pixel column of this row under the tap
+    bool ok = true;
+    if (reflect) ix = ix < 0 ? -ix : (ix >= W ? 2 * W - 2 - ix : ix);
+    else ok = (unsigned)ix < (unsigned)W;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      goff[hf][jj] = (unsigned)(row * Co + co0 + 64 * hf) * 2u;
+      xoff[hf][jj] = ok ? (unsigned)(ix * Ci + kc0 + 32 * hf) * 2u : OOB_OFF;
+    }
+  }
+  // per-region stream state (wave-uniform): next K-tile
+  int a_kt[2] = {0, 0}, b_kt[2] = {0, 0};
+  int b_b[2], b_oy[2];  // sample / image row of the B regions' next K-tile
+  b_b[0] = b_b[1] = r_begin / H;
+  b_oy[0] = b_oy[1] = r_begin - b_b[0] * H;
+
+  auto issue_a = [&](int r) {
+    const int kt = a_kt[r];
+    const bool live = kt < nk;
+    char* dst = smem + (kt & 1) * BUFB + r * REG;
+    const unsigned soff = live ? (unsigned)(r_begin + kt) * (unsigned)(W * Co * 2) : 0u;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(gr, (lds_void*)(dst + (2 * wave + jj) * 1024), 16,
+                                               (int)(live ? goff[r][jj] : OOB_OFF), (int)soff, 0, 0);
+    a_kt[r] = kt + 1;
+  };
+  auto issue_b = [&](int r) {
+    const int kt = b_kt[r];
+    int iy = b_oy[r] + dy;
+    bool live = kt < nk;
+    if (reflect) iy = iy < 0 ? -iy : (iy >= H ? 2 * H - 2 - iy : iy);
+    else live = live && (unsigned)iy < (unsigned)H;
+    char* dst = smem + (kt & 1) * BUFB + (2 + r) * REG;
+    const unsigned soff = live ? (unsigned)((b_b[r] * H + iy) * W) * (unsigned)(Ci * 2) : 0u;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void*)(dst + (2 * wave + jj) * 1024), 16,
+                                               (int)(live ? xoff[r][jj] : OOB_OFF), (int)soff, 0, 0);
+    b_kt[r] = kt + 1;
+    if (++b_oy[r] == H) { b_oy[r] = 0; ++b_b[r]; }
+  };
+
+  // ---- fragments (transposing reads) --------------------------------------------------------------------
+  // lane = 16 g + 4 q + p: k-group g (pixel rows 8 g .. 8 g + 7 of a 32-row k-step), block row q, column quad p
+  const int g = lane >> 4, q = (lane >> 2) & 3, pq = lane & 3;
+  const int fsw = (q << 1) | ((g & 1) << 3);
+  const int fa0 = (8 * g + q) * 256 + (((8 * wrow + (pq >> 1)) ^ fsw) << 4) + 8 * (pq & 1);
+  const int fb0 = (8 * g + q) * 256 + (((4 * wcol + (pq >> 1)) ^ fsw) << 4) + 8 * (pq & 1) + 2 * REG;
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  auto tr8 = [&](const char* a) {  // 8 consecutive pixel rows of this lane's column: two transposing reads
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 1024));
+    const s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, r);
+  };
+  bf16x8 af[4][2], b0f[2][2], b1f[2][2];
+  auto read_a = [&](int buf, int mh) {
+    const char* base = smem + buf * BUFB + mh * REG;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) af[i][ks] = tr8(base + ((fa0 ^ (i << 5)) + ks * 8192));
+  };
+  auto read_b = [&](bf16x8 (&bf)[2][2], int buf, int nh) {
+    const char* base = smem + buf * BUFB + nh * REG;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) bf[j][ks] = tr8(base + ((fb0 ^ (j << 5)) + ks * 8192));
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto multiply = [&](const bf16x8 (&bf)[2][2], int mh, int nh) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[mh * 4 + i][nh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][ks], bf[j][ks], acc[mh * 4 + i][nh * 2 + j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+#define WP8_WAIT_AND_SYNC()                                 \
+  do {                                                      \
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        \
+    __builtin_amdgcn_s_barrier();                           \
+  } while (0)
+
+  // ---- prologue / main loop: the schedule of conv_igemm_p8_kernel, region for region ----------------------
+  issue_b(0);  // B0(0)
+  issue_a(0);  // A0(0)
+  issue_b(1);  // B1(0)
+  issue_a(1);  // A1(0)
+  issue_b(0);  // B0(1)
+  issue_a(0);  // A0(1)
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // B0(0), A0(0) have landed for every wave
+  __builtin_amdgcn_s_barrier();
+  if (wrow == 1) __builtin_amdgcn_s_barrier();  // this wave row runs one barrier behind the other
+  read_b(b0f, 0, 0);
+  for (int t = 0; t < nk; ++t) {
+    const int cur = t & 1;
+    read_a(cur, 0);  // p1: A0 x B0
+    issue_b(1);      // B1(t+1)
+    WP8_WAIT_AND_SYNC();
+    multiply(b0f, 0, 0);
+    __builtin_amdgcn_s_barrier();
+    read_b(b1f, cur, 1);  // p2: A0 x B1
+    issue_a(1);           // A1(t+1)
+    WP8_WAIT_AND_SYNC();
+    multiply(b1f, 0, 1);
+    __builtin_amdgcn_s_barrier();
+    read_a(cur, 1);  // p3: A1 x B1
+    issue_b(0);      // B0(t+2)
+    WP8_WAIT_AND_SYNC();
+    multiply(b1f, 1, 1);
+    __builtin_amdgcn_s_barrier();
+    issue_a(0);  // p4: A1 x B0, then the next K-tile's B0 fragments (landed: waited for at the end of p3)
+    WP8_WAIT_AND_SYNC();
+    multiply(b0f, 1, 0);
+    read_b(b0f, cur ^ 1, 0);
+    __builtin_amdgcn_s_barrier();
+  }
+#undef WP8_WAIT_AND_SYNC
+  if (wrow == 0) __builtin_amdgcn_s_barrier();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the zero fills issued past the end of the reduction
+  __syncthreads();
+
+  // ---- epilogue: fp32 tile through LDS -> the slice's slab, whole 16-B vectors of a filter row ---------------
+  constexpr int CSTR = 256 + 4;
+  float* csm = reinterpret_cast<float*>(smem);
+  float* __restrict__ slab = d.slabs + ((size_t)split * Co) * K + (size_t)tap * Ci;
+  const int ec4 = tid & 63, erow = tid >> 6;  // float4 column, row within the 8 rows of an iteration
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass == wrow) {
+      // C/D of 16x16x32: column = lane & 15, row = 4 (lane >> 4) + register
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            csm[(i * 16 + 4 * (lane >> 4) + r) * CSTR + wcol * 64 + j * 16 + (lane & 15)] = acc[i][j][r];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+      const int row = erow + it * 8;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(csm + row * CSTR + ec4 * 4);
+      *reinterpret_cast<f32x4*>(slab + (size_t)(pass * 128 + row) * K + ec4 * 4) = v;
+    }
+    if (pass == 0) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+}
+
+// the layers the phase-pipelined weight-gradient kernel takes; *splits / *rows: its slicing of the image rows
+inline bool wgrad_p8_ok(const o2m_wgrad_desc& d, long* splits, long* rows) {
+  static const int on = [] { const char* e = getenv("O2M_WGRAD_P8"); return e ? atoi(e) : 1; }();
+  if (!on || d.dtype != O2M_BF16 || d.Co != 256 || d.Ci != 256 || d.KH != 3 || d.KW != 3 || d.pad != 1 || d.stride > 1 ||
+      d.W != 64 || d.in_scale || d.gy_scale || d.nseg > 1 || d.splits > 0)
+    return false;
+  const long r_total = (long)d.B * d.H;
+  if (r_total < 28 * 8) return false;  // >= 8 K-tiles per slice
+  const long per = (r_total + 27) / 28;  // 9 taps x 28 slices = 252 blocks: one per CU
+  *rows = per;
+  *splits = (r_total + per - 1) / per;
+  return true;
+}
+
 // slab_floats != nullptr: only report the workspace the launch would need
 template <typename T, int BCO, int BKO, int WAVES_CO, int WAVES_K>
 int launch_cfg(const o2m_wgrad_desc& d, hipStream_t s, size_t* slab_floats = nullptr) {
@@ -444,7 +675,50 @@ int launch_cfg(const o2m_wgrad_desc& d, hipStream_t s, size_t* slab_floats = nul
 }
 
 template <typename T>
+int launch_dtype_r2(const o2m_wgrad_desc& d, hipStream_t s, size_t* slab_floats = nullptr);
+
+int launch_wgrad_p8(const o2m_wgrad_desc& d, hipStream_t s, long splits, long rows, size_t* slab_floats) {
+  const int K = 9 * d.Ci;
+  if (slab_floats) {
+    *slab_floats = (size_t)splits * d.Co * K;
+    return 0;
+  }
+  constexpr int lds = 128 * (256 + 4) * 4;  // >= the two 64 KB K-tile buffers
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_p8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  {
+    LaunchScope timed(s, 2.0 * d.B * d.H * d.W * d.Co * K, "%s", "conv_wgrad_p8<bf16,256x256>");
+    hipLaunchKernelGGL(conv_wgrad_p8_kernel, dim3((unsigned)(9 * splits)), dim3(512), lds, s, d, (int)rows);
+  }
+  O2M_LAUNCH_CHECK();
+  const long n4 = (long)d.Co * K / 4;
+  LaunchScope timed(s, 0.0, "%s", "wgrad_reduce");
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, d.dw, d.slabs, (int)splits, n4);
+  O2M_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename T>
 int launch_dtype(const o2m_wgrad_desc& d, hipStream_t s, size_t* slab_floats = nullptr) {
+  if constexpr (sizeof(T) == 2) {
+    long splits = 0, rows = 0;
+    // (slab mode only: the atomic form, O2M_WGRAD_ATOMICS=1, keeps the round-2 kernels; a size query cannot know
+    // the mode, and both kernels fit the larger of the two workspaces)
+    if (wgrad_p8_ok(d, &splits, &rows)) {
+      if (slab_floats) {
+        size_t a = 0, b = 0;
+        (void)launch_wgrad_p8(d, s, splits, rows, &a);
+        (void)launch_dtype_r2<T>(d, s, &b);
+        *slab_floats = a > b ? a : b;
+        return 0;
+      }
+      if (d.slabs) return launch_wgrad_p8(d, s, splits, rows, nullptr);
+    }
+  }
+  return launch_dtype_r2<T>(d, s, slab_floats);
+}
+
+template <typename T>
+int launch_dtype_r2(const o2m_wgrad_desc& d, hipStream_t s, size_t* slab_floats) {
   // O2M_WGRAD_TILES=small keeps the 128-wide tiles (A/B measurements)
   static const bool small = [] { const char* e = getenv("O2M_WGRAD_TILES"); return e && e[0] == 's'; }();
   const int K = d.KH * d.KW * d.Ci;

@@ -681,3 +681,35 @@ def test_halo_kernel_instance_norm_partials_match_the_statistics_pass(co):
     # (the epilogue sums the fp32 accumulators, the pass the bf16-rounded y)
     assert float((mr[..., 0] - mr0[..., 0]).abs().max()) < 2e-3
     assert float(((mr[..., 1] - mr0[..., 1]) / mr0[..., 1]).abs().max()) < 2e-3
+
+
+@pytest.mark.parametrize("reflect", [True, False], ids=["reflect", "zero"])
+def test_phase_pipelined_weight_gradient_matches_torch(reflect):
+    """conv_wgrad_p8_kernel (256 -> 256, 3 x 3, 64-pixel rows; transposing LDS reads, LDS-DMA fills, slabs) against
+    torch's fp32 weight gradient of the same bf16-valued operands, for both paddings and an uneven last slice."""
+    import torch.nn.functional as F
+
+    from one_to_many_gan_amd import _hip as H
+
+    torch.manual_seed(21)
+    for B in (4, 7):  # 256 / 448 image rows over 28 slices: even / uneven
+        x = torch.randn(B, 64, 64, 256, device="cuda").bfloat16()
+        g = torch.randn(B, 64, 64, 256, device="cuda").bfloat16()
+        dw = torch.zeros(256, 3, 3, 256, device="cuda")
+        pm = H.PAD_REFLECT if reflect else H.PAD_ZERO
+        H.launch_timing(True)
+        try:
+            H.conv2d_wgrad(x, g, dw, pad=1, pad_mode=pm)
+            torch.cuda.synchronize()
+            names = set(H.launch_timing_read())
+        finally:
+            H.launch_timing(False)
+        assert "conv_wgrad_p8<bf16,256x256>" in names, names
+        xin = x.float().permute(0, 3, 1, 2)
+        xin = F.pad(xin, (1,) * 4, mode="reflect") if reflect else F.pad(xin, (1,) * 4)
+        ref = torch.nn.grad.conv2d_weight(xin, (256, 256, 3, 3), g.float().permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+        err = float((dw - ref).norm() / ref.norm())
+        assert err < 2e-5, (B, reflect, err)
+        # every tap and channel block individually (a mis-staged region would hide in the norm of the whole)
+        per_tap = ((dw - ref) ** 2).sum(dim=(0, 3)).sqrt() / (ref ** 2).sum(dim=(0, 3)).sqrt()
+        assert float(per_tap.max()) < 5e-5, per_tap

@@ -17,6 +17,17 @@ SHAPES = [  # B, H, W, Ci, Co, k, pad, reflect
     (16, 127, 127, 64, 128, 4, 1, False),
     (16, 63, 63, 128, 256, 4, 1, False),
     (16, 31, 31, 256, 512, 4, 1, False),
+    # round 3: the batched decoder groups (3B = 48, 2B = 32) and the encoder's 2B
+    (48, 64, 64, 256, 256, 3, 1, True),
+    (48, 128, 128, 256, 128, 3, 1, False),
+    (48, 128, 128, 128, 256, 3, 1, False),
+    (48, 256, 256, 128, 64, 3, 1, False),
+    (48, 256, 256, 64, 128, 3, 1, False),
+    (32, 256, 256, 64, 128, 3, 1, False),
+    (32, 128, 128, 128, 256, 3, 1, False),
+    (32, 127, 127, 64, 128, 4, 1, False),
+    (32, 63, 63, 128, 256, 4, 1, False),
+    (32, 31, 31, 256, 512, 4, 1, False),
 ]
 
 
