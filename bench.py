@@ -164,12 +164,13 @@ def kernel_profile(trainer, precision, steps=3):
     # kernels (that is its point: -1.5 ms/step), which lengthens each of them by ~8 %.  The un-overlapped duration
     # is the kernel's own figure; it is reported next to the in-step one, not instead of it.
     alone = None
-    if getattr(o2m_ops, "_WGRAD_STREAM", False):
-        o2m_ops._WGRAD_STREAM = False
+    if getattr(o2m_ops, "_WGRAD_STREAM", False) or getattr(o2m_ops, "_GROUP_STREAM", False):
+        saved = (o2m_ops._WGRAD_STREAM, o2m_ops._GROUP_STREAM)
+        o2m_ops._WGRAD_STREAM = o2m_ops._GROUP_STREAM = False  # one stream: every kernel has the chip to itself
         try:
             alone = timed_steps()
         finally:
-            o2m_ops._WGRAD_STREAM = True
+            o2m_ops._WGRAD_STREAM, o2m_ops._GROUP_STREAM = saved
     total_conv_s = sum(a[1] for a in agg.values())
     name, (n, secs, flops) = max(agg.items(), key=lambda kv: kv[1][1])
     achieved = flops / secs / 1e12
@@ -195,11 +196,60 @@ def kernel_profile(trainer, precision, steps=3):
             "achieved": round(alone[name][2] / alone[name][1] / 1e12, 2),
             "frac": round(alone[name][2] / alone[name][1] / 1e12 / peak, 4),
             "avg_launch_us": round(alone[name][1] / alone[name][0] * 1e6, 2),
-            "note": "same steps with the weight-gradient kernels on the main stream (nothing runs beside the kernel)"}),
+            "note": "same steps on ONE stream: the weight-gradient stream and the extraction-group stream folded into "
+                    "the main one, so nothing runs beside the kernel"}),
         "share_of_conv_time": round(secs / total_conv_s, 3),
         "all_conv_kernels": {k: {"launches": round(v[0], 1), "ms": round(v[1] * 1e3, 3),
                                  "tflops": round(v[2] / v[1] / 1e12, 1)} for k, v in sorted(agg.items())},
     }
+
+
+def count_dispatches(trainer):
+    """Operator dispatches of ONE step (a proxy for its kernel launches: every o2m:: op is one launch, two for the
+    weight gradient and the InstanceNorm backward; view / metadata aten ops are not counted)."""
+    from torch.utils._python_dispatch import TorchDispatchMode
+
+    skip = ("aten.empty", "aten.as_strided", "aten.slice", "aten.detach", "aten.view", "aten.select", "aten.permute",
+            "aten.t.", "aten.transpose", "aten.alias", "aten.expand", "aten.unsqueeze", "aten.record_stream",
+            "aten._unsafe_view", "aten.reshape", "aten.narrow", "aten.squeeze", "aten.unbind", "aten.split", "aten.chunk",
+            "aten.is_pinned", "aten._local_scalar_dense", "aten.lift_fresh", "aten.sym_")
+    n = {"o2m": 0, "aten": 0}
+
+    class Count(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            name = str(func)
+            if name.startswith("o2m."):
+                n["o2m"] += 1
+            elif not name.startswith(skip):
+                n["aten"] += 1
+            return func(*args, **(kwargs or {}))
+
+    with Count():
+        trainer.step()
+    torch.cuda.synchronize()
+    return {"o2m_ops": n["o2m"], "aten_ops": n["aten"], "note": "operator dispatches of one D+G step"}
+
+
+def extra_leg(args, device, precision, size, batch, steps=5, warmup=2):
+    """One more configuration timed in the same run (BASELINE configs #4 and #5), a few steps each."""
+    cfg = make_config(size, args.channels, batch)
+    tr = Trainer(product_namespace(precision), cfg, device)
+    for _ in range(warmup):
+        tr.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    out = {"workload": f"{size}x{size}x{args.channels}, batch {batch}, {precision}", "ms_per_step": round(dt * 1e3, 3),
+           "value": round(batch / dt, 3), "unit": "images/sec", "steps": steps, "warmup": warmup}
+    flop = FLOP_PER_IMAGE_STEP.get((size, args.channels))
+    if flop:
+        out["step_mfma_frac"] = round(batch / dt * flop / MFMA_PEAK[precision], 4)
+    del tr
+    torch.cuda.empty_cache()
+    return out
 
 
 def cpu_baseline(size, channels, timed_steps=3, batch=2):
@@ -287,6 +337,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the fp32-split (1e-3 parity gate) leg")
     ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the fp8 (config #5) and 512x512 (config #4) legs")
     ap.add_argument("--dump-params", default=None, help="write a checksum of every rank's weights (tests)")
     args = ap.parse_args()
 
@@ -370,12 +421,16 @@ def main():
         if world > 1:
             trainer.ada_p.update_p = trainer.ada_p.local_update_p  # undo dist.sync_ada_p's all-reduce
         out["roofline"] = kernel_profile(trainer, args.precision)
+        out["dispatches_per_step"] = count_dispatches(trainer)
     if world > 1:
         dist.barrier()
     if rank == 0 and world == 1 and not args.no_parity_mode and args.precision == "bf16":
         del trainer
         torch.cuda.empty_cache()
         out["parity_mode"] = parity_mode_leg(args, device)
+        if (args.size, args.batch) == (256, 16) and not args.no_extra_legs:
+            out["fp8_mode"] = extra_leg(args, device, "fp8", 256, 16)     # BASELINE config #5
+            out["config4"] = extra_leg(args, device, "bf16", 512, 8)      # BASELINE config #4 (one GPU's share)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.size, args.channels)
     if rank == 0:

@@ -670,33 +670,6 @@ long tiles_for(const o2m_conv_desc& d) {
 // =============================================================================================
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
-// Diagnostic build only (-DO2M_P8_STAMPS, tools/stamp_conv.py): s_memtime stamps around the segments of
-// a phase, summed per wave in scalar registers; never compiled into libo2m_hip.so.
-#ifdef O2M_P8_STAMPS
-__device__ unsigned long long o2m_p8_stamps[2][8];
-__device__ unsigned long long o2m_p8_estamps[2][12];  // epilogue timeline (absolute s_memtime values)
-#define P8_ESTAMP(i)                                                                       \
-  do {                                                                                     \
-    __builtin_amdgcn_sched_barrier(0);                                                     \
-    unsigned long long t_;                                                                 \
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
-    __builtin_amdgcn_sched_barrier(0);                                                     \
-    if (blockIdx.x == 7 && (wave == 0 || wave == 4) && lane == 0) o2m_p8_estamps[wave >> 2][i] = t_; \
-  } while (0)
-#define P8_STAMP(i)                                                                        \
-  do {                                                                                     \
-    __builtin_amdgcn_sched_barrier(0);                                                     \
-    unsigned long long t_;                                                                 \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");             \
-    __builtin_amdgcn_sched_barrier(0);                                                     \
-    st_sum[i] += t_ - st_last;                                                             \
-    st_last = t_;                                                                          \
-  } while (0)
-#else
-#define P8_STAMP(i) do {} while (0)
-#define P8_ESTAMP(i) do {} while (0)
-#endif
-
 // FMT: element format of the MFMA operands.  0 = bf16 (x, w, y bf16: v_mfma_f32_16x16x32_bf16).
 // 1 / 2 = BASELINE config #5, the fp8 path: x is OCP e4m3 (1) or e5m2 (2, gradients), w is e4m3, y / residual are
 // bf16, products on v_mfma_f32_16x16x32_{fp8,bf8}_fp8 with fp32 accumulation and one dequantisation factor
@@ -885,27 +858,14 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
         }
     __builtin_amdgcn_s_setprio(0);
   };
-#ifdef O2M_P8_STAMPS
-  unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0;
-#endif
-  // stamp slots: 0 reads + fill issue, 1 vmcnt wait, 2 barrier before the MFMAs, 3 MFMAs, 4 closing barrier
 #define P8_WAIT_AND_SYNC()                                  \
   do {                                                      \
-    P8_STAMP(0);                                            \
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        \
-    P8_STAMP(1);                                            \
     __builtin_amdgcn_s_barrier();                           \
-    P8_STAMP(2);                                            \
   } while (0)
-#define P8_CLOSE()                                          \
-  do {                                                      \
-    P8_STAMP(3);                                            \
-    __builtin_amdgcn_s_barrier();                           \
-    P8_STAMP(4);                                            \
-  } while (0)
+#define P8_CLOSE() __builtin_amdgcn_s_barrier()
 
   // ---- prologue: regions needed by phases -1 .. 4 -------------------------------------------------------
-  P8_ESTAMP(0);
   issue_b(0);  // B0(0)
   issue_a(0);  // A0(0)
   issue_b(1);  // B1(0)
@@ -916,36 +876,28 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
   __builtin_amdgcn_s_barrier();
   if (wrow == 1) __builtin_amdgcn_s_barrier();  // this wave row runs one barrier behind the other
   read_b(b0f, 0, 0);
-#ifdef O2M_P8_STAMPS
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
-  for (int i = 0; i < 8; ++i) st_sum[i] = 0;
-#endif
 
   for (int t = 0; t < nk; ++t) {
     const int cur = t & 1;
     // p1: A0 x B0
     read_a(cur, 0);
-    P8_STAMP(5);
     issue_b(1);  // B1(t+1)
     P8_WAIT_AND_SYNC();
     multiply(b0f, 0, 0);
     P8_CLOSE();
     // p2: A0 x B1
     read_b(b1f, cur, 1);
-    P8_STAMP(5);
     issue_a(1);  // A1(t+1)
     P8_WAIT_AND_SYNC();
     multiply(b1f, 0, 1);
     P8_CLOSE();
     // p3: A1 x B1
     read_a(cur, 1);
-    P8_STAMP(5);
     issue_b(0);  // B0(t+2)
     P8_WAIT_AND_SYNC();
     multiply(b1f, 1, 1);
     P8_CLOSE();
     // p4: A1 x B0, then the next K-tile's B0 fragments (landed: waited for at the end of p3)
-    P8_STAMP(5);
     issue_a(0);  // A0(t+2)
     P8_WAIT_AND_SYNC();
     multiply(b0f, 1, 0);
@@ -954,16 +906,9 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
   }
 #undef P8_WAIT_AND_SYNC
 #undef P8_CLOSE
-#ifdef O2M_P8_STAMPS
-  if (blockIdx.x == 7 && (wave == 0 || wave == 4) && lane == 0) {
-    for (int i = 0; i < 8; ++i) o2m_p8_stamps[wave >> 2][i] = st_sum[i];
-  }
-#endif
-  P8_ESTAMP(1);
   if (wrow == 0) __builtin_amdgcn_s_barrier();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the zero fills issued past the end of the reduction
   __syncthreads();
-  P8_ESTAMP(2);
 
   // ---- epilogue: fp32 tile through LDS, whole channel vectors out (as in conv_igemm_kernel) -------------
   constexpr int CSTR = BN + 4;
@@ -975,7 +920,10 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
   const float deq = (FMT != 0 && d.deq_scale) ? d.deq_scale[0] * d.deq_scale[2] : 1.f;  // {1/scale, amax} of x, of w
   // outputs of >= 64 MiB leave through non-temporal stores, as in conv_igemm_kernel (no cache level holds them for
   // the consumer; written normally they evict the input lines the taps re-read)
-  const bool stream_out = (size_t)M * Co * sizeof(T) >= ((size_t)64 << 20);
+#ifndef O2M_P8_STREAM_OUT
+#define O2M_P8_STREAM_OUT 1  // (0: A/B builds, tools/build_variant.sh)
+#endif
+  const bool stream_out = O2M_P8_STREAM_OUT && (size_t)M * Co * sizeof(T) >= ((size_t)64 << 20);
   const bool dot_mode = d.stats && d.stats_mode == O2M_STATS_DOT;
   const T* __restrict__ AUX = static_cast<const T*>(d.aux);
   T* __restrict__ AUXS = static_cast<T*>(d.aux_scaled);
@@ -1010,9 +958,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
           for (int r = 0; r < 4; ++r)
             csm[(i * 16 + 4 * (lane >> 4) + r) * CSTR + wcol * 64 + j * 16 + (lane & 15)] = acc[i][j][r];
     }
-    if (pass == 0) P8_ESTAMP(3); else P8_ESTAMP(7);
     lds_barrier();
-    if (pass == 0) P8_ESTAMP(4); else P8_ESTAMP(8);
     const int mbase = m0 + pass * 128;
     float st[16];
 #pragma unroll
@@ -1071,9 +1017,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
       store8x(Y + off, o, stream_out);
     }
     if (d.stats && mbase < M) stats_block_reduce<NT, VPR>(st, csm, d.stats, (long)(mbase / 128), n0, Co, tid);
-    if (pass == 0) P8_ESTAMP(5); else P8_ESTAMP(9);
     if (pass == 0) lds_barrier();
-    if (pass == 0) P8_ESTAMP(6);
   }
 }
 
@@ -1425,15 +1369,6 @@ static int stats_rows_for(const o2m_conv_desc& d) {
   return 64;  // 256x64 / 256x128 (4 wave rows), 128x128 / 128x64 (2 wave rows), 256x32
 }
 
-#ifdef O2M_P8_STAMPS
-extern "C" int o2m_debug_estamps(unsigned long long* out) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(o2m_p8_estamps), sizeof(unsigned long long) * 24);
-}
-extern "C" int o2m_debug_stamps(unsigned long long* out) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(o2m_p8_stamps), sizeof(unsigned long long) * 16);
-}
-#endif
-
 namespace {
 // dots[b][c] = sum over the row blocks of a sample of the epilogue's O2M_STATS_DOT partials, in block order
 __global__ __launch_bounds__(256) void dots_finalize_kernel(const float* __restrict__ partial, float* __restrict__ dots,
@@ -1476,9 +1411,35 @@ extern "C" int o2m_conv2d_fwd(const o2m_conv_desc* d, void* stream) {
   if (d->pad_mode != O2M_PAD_ZERO && d->pad_mode != O2M_PAD_REFLECT) return O2M_ERR_BAD_ARG;
   const bool f8 = d->dtype == O2M_FP8_E4M3 || d->dtype == O2M_BF8_E5M2;
   const long esz = d->dtype == O2M_F32 ? 4 : (f8 ? 1 : 2);
-  // buffer descriptors address < 2 GiB per tensor (offset 0x80000000 marks "out of range")
-  if ((long)d->B * d->H * d->W * (long)d->Ci * esz > 0x7fffffffL) return O2M_ERR_UNSUPPORTED;
   if (d->w_batch_stride < 0) return O2M_ERR_BAD_ARG;
+  // Buffer descriptors address < 2 GiB per tensor (offset 0x80000000 marks "out of range"): a larger input (fp32
+  // parity mode at BASELINE config #4: 16 x 512 x 512 x 128 floats = 2 GiB) is run as several launches over
+  // slices of the batch -- every sample's rows are independent, so the result is that of one launch.
+  const long x_sample = (long)d->H * d->W * (long)d->Ci * esz;
+  if (x_sample > 0x7fffffffL) return O2M_ERR_UNSUPPORTED;
+  if ((long)d->B * x_sample > 0x7fffffffL) {
+    const int S_ = d->stride > 1 ? d->stride : 1;
+    const long howo = (long)((d->H + 2 * d->pad - d->KH) / S_ + 1) * ((d->W + 2 * d->pad - d->KW) / S_ + 1);
+    const long ysz = d->dtype == O2M_F32 ? 4 : 2;  // (fp8 operands produce bf16)
+    const int per = (int)(0x7fffffffL / x_sample);
+    const int rows = d->stats ? o2m_conv2d_stats_rows(d) : 0;
+    for (int b0 = 0; b0 < d->B; b0 += per) {
+      o2m_conv_desc c = *d;
+      c.B = d->B - b0 < per ? d->B - b0 : per;
+      c.x = static_cast<const char*>(d->x) + (size_t)b0 * x_sample;
+      c.y = static_cast<char*>(d->y) + (size_t)b0 * howo * d->Co * ysz;
+      if (d->residual) c.residual = static_cast<const char*>(d->residual) + (size_t)b0 * howo * d->Co * ysz;
+      if (d->aux) c.aux = static_cast<const char*>(d->aux) + (size_t)b0 * howo * d->Co * ysz;
+      if (d->aux_scaled) c.aux_scaled = static_cast<char*>(d->aux_scaled) + (size_t)b0 * howo * d->Co * ysz;
+      if (d->in_scale) c.in_scale = d->in_scale + (size_t)b0 * d->Ci;
+      if (d->out_scale) c.out_scale = d->out_scale + (size_t)b0 * d->Co;
+      if (d->w_batch_stride > 0) c.w = static_cast<const char*>(d->w) + (size_t)b0 * d->w_batch_stride * esz;
+      if (d->stats && rows > 0) c.stats = d->stats + (size_t)b0 * (howo / rows) * d->Co * 2;
+      const int rc = o2m_conv2d_fwd(&c, stream);
+      if (rc) return rc;
+    }
+    return 0;
+  }
   if ((long)d->Co * d->KH * d->KW * (long)d->Ci * esz > 0x7fffffffL) return O2M_ERR_UNSUPPORTED;
   if (d->stride < 0 || d->stride > 16) return O2M_ERR_BAD_ARG;
   if (d->w_batch_stride > 0) {

@@ -759,8 +759,30 @@ static int wgrad_run(const o2m_wgrad_desc* d, void* stream, size_t* slab_floats)
   if (d->stride < 0 || d->stride > 8) return O2M_ERR_BAD_ARG;
   const int st = d->stride > 0 ? d->stride : 1;
   const long howo = (long)((d->H + 2 * d->pad - d->KH) / st + 1) * ((d->W + 2 * d->pad - d->KW) / st + 1);
-  if ((long)d->B * d->H * d->W * (long)d->Ci * esz > 0x7fffffffL) return O2M_ERR_UNSUPPORTED;
-  if ((long)d->B * howo * (long)d->Co * esz > 0x7fffffffL) return O2M_ERR_UNSUPPORTED;
+  // Buffer descriptors address < 2 GiB per tensor: larger operands (fp32 parity mode at 512 x 512) are reduced as
+  // several launches over slices of the batch, each adding its slab sum into dw (fixed order).
+  const long x_sample = (long)d->H * d->W * (long)d->Ci * esz, g_sample = howo * (long)d->Co * esz;
+  if (x_sample > 0x7fffffffL || g_sample > 0x7fffffffL) return O2M_ERR_UNSUPPORTED;
+  if ((long)d->B * x_sample > 0x7fffffffL || (long)d->B * g_sample > 0x7fffffffL) {
+    if (d->nseg > 1) return O2M_ERR_UNSUPPORTED;
+    const long big = x_sample > g_sample ? x_sample : g_sample;
+    const int per = (int)(0x7fffffffL / big);
+    size_t most = 0;
+    for (int b0 = 0; b0 < d->B; b0 += per) {
+      o2m_wgrad_desc c = *d;
+      c.B = d->B - b0 < per ? d->B - b0 : per;
+      c.x = static_cast<const char*>(d->x) + (size_t)b0 * x_sample;
+      c.gy = static_cast<const char*>(d->gy) + (size_t)b0 * g_sample;
+      if (d->in_scale) c.in_scale = d->in_scale + (size_t)b0 * d->Ci;
+      if (d->gy_scale) c.gy_scale = d->gy_scale + (size_t)b0 * d->Co;
+      size_t n = 0;
+      const int rc = wgrad_run(&c, stream, slab_floats ? &n : nullptr);
+      if (rc) return rc;
+      if (n > most) most = n;
+    }
+    if (slab_floats) *slab_floats = most;
+    return 0;
+  }
   if (d->nseg < 0 || d->nseg > 8) return O2M_ERR_BAD_ARG;
   if (d->nseg > 1) {
     const int wo = (d->W + 2 * d->pad - d->KW) / st + 1;

@@ -510,6 +510,30 @@ __global__ __launch_bounds__(NT) void resample2x2_kernel(const T* __restrict__ x
 // two 1-D passes this replaces moved the intermediate map through HBM and ran their row walk at ~2 TB/s.
 // The vertical weights are block-uniform: re-indexed on the patch rows (zero outside an output's band) they
 // sit in SGPRs and the row walk has only static register indices.
+template <typename T> struct RawVec;  // 8 consecutive channels as loaded (unpacked to floats on use)
+template <> struct RawVec<unsigned short> {
+  u32x4 v;
+  __device__ __forceinline__ void load(const unsigned short* p) { v = *reinterpret_cast<const u32x4*>(p); }
+  __device__ __forceinline__ void unpack(float (&f)[8]) const {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f[2 * i] = __builtin_bit_cast(float, v[i] << 16);
+      f[2 * i + 1] = __builtin_bit_cast(float, v[i] & 0xffff0000u);
+    }
+  }
+};
+template <> struct RawVec<float> {
+  f32x4 a, b;
+  __device__ __forceinline__ void load(const float* p) {
+    a = *reinterpret_cast<const f32x4*>(p);
+    b = *reinterpret_cast<const f32x4*>(p + 4);
+  }
+  __device__ __forceinline__ void unpack(float (&f)[8]) const {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[i] = a[i]; f[4 + i] = b[i]; }
+  }
+};
+
 template <typename T, int TY, int TX, int SY, int SX, int OH, int OW>
 __global__ __launch_bounds__(NT) void resample_tile_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                            const int* __restrict__ sy, const float* __restrict__ wy,
@@ -520,50 +544,70 @@ __global__ __launch_bounds__(NT) void resample_tile_kernel(const T* __restrict__
   const int chunk = blockIdx.x / tiles_x, tx_ = blockIdx.x - chunk * tiles_x;
   const int ox0 = tx_ * OW, oy0 = blockIdx.y * OH, b = blockIdx.z;
   const int y_start = sy[oy0], x_start = sx[ox0];
-  // vertical weights of the OH output rows on the PH patch rows (block-uniform -> scalar registers)
-  // (unconditional loads + selects: as `cond ? wy[...] : 0` every entry became its own scalar load behind its own
-  // branch and wait -- ~45 dependent scalar-cache round trips, ~25 us of prologue per block)
-  float cy[OH][PH];
-#pragma unroll
-  for (int o = 0; o < OH; ++o) {
-    const int oy = min(oy0 + o, Ho - 1);
-    const int off = sy[oy] - y_start;  // 0 .. SY * o
-    float wrow[TY];
-#pragma unroll
-    for (int t = 0; t < TY; ++t) wrow[t] = wy[oy * TY + t];
-#pragma unroll
-    for (int k = 0; k < PH; ++k) {
-      float c = 0.f;
-#pragma unroll
-      for (int t = 0; t < TY; ++t) c = (k - off == t) ? wrow[t] : c;
-      cy[o][k] = c;
-    }
-  }
   const T* base = x + ((size_t)b * H * W) * C + (size_t)chunk * CVB * 8;
   f32x4* sm4 = reinterpret_cast<f32x4*>(sm);
   // ---- phase A -------------------------------------------------------------------------------------
+  // Regular tiles (everything but the image's first / last tile rows): output row o starts exactly SY * o patch
+  // rows below the tile's first, so the vertical taps index the preloaded rows STATICALLY and the TY weights per
+  // output row are block-uniform scalars.  (Re-indexing the weights on the patch rows for every tile -- the first
+  // version -- needs OH x PH uniform values: past the scalar file, 239 VGPRs, and twice the multiply-adds.)
+  bool regular = true;
+#pragma unroll
+  for (int o = 0; o < OH; ++o) regular = regular && (oy0 + o < Ho) && (sy[min(oy0 + o, Ho - 1)] - y_start == SY * o);
   for (int item = threadIdx.x; item < PW * CVB; item += NT) {
     const int pc = item / CVB, cv = item - pc * CVB;
     const int ix = min(x_start + pc, W - 1);
-    float acc[OH][8];
+    const T* col = base + (size_t)ix * C + cv * 8;
+    if (regular) {
+      RawVec<T> raw[PH];  // all PH row loads in flight as raw 16-B (32-B) vectors, unpacked one row at a time
 #pragma unroll
-    for (int o = 0; o < OH; ++o)
-#pragma unroll
-      for (int i = 0; i < 8; ++i) acc[o][i] = 0.f;
-    float v[PH][8];
-#pragma unroll
-    for (int r = 0; r < PH; ++r) load8(base + ((size_t)min(y_start + r, H - 1) * W + ix) * C + cv * 8, v[r]);
-#pragma unroll
-    for (int r = 0; r < PH; ++r)
+      for (int r = 0; r < PH; ++r) raw[r].load(col + (size_t)min(y_start + r, H - 1) * W * C);
+      float acc[OH][8];
 #pragma unroll
       for (int o = 0; o < OH; ++o)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[o][i] += cy[o][r] * v[r][i];
+        for (int i = 0; i < 8; ++i) acc[o][i] = 0.f;
 #pragma unroll
-    for (int o = 0; o < OH; ++o) {
-      f32x4* dst = sm4 + ((size_t)(o * PW + pc) * 2) * CVB + cv;
-      dst[0] = f32x4{acc[o][0], acc[o][1], acc[o][2], acc[o][3]};
-      dst[CVB] = f32x4{acc[o][4], acc[o][5], acc[o][6], acc[o][7]};
+      for (int r = 0; r < PH; ++r) {
+        float v[8];
+        raw[r].unpack(v);
+#pragma unroll
+        for (int o = 0; o < OH; ++o) {
+          const int t = r - SY * o;  // compile-time
+          if (t >= 0 && t < TY) {
+            const float w = wy[(oy0 + o) * TY + t];  // block-uniform: a scalar load
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[o][i] += w * v[i];
+          }
+        }
+      }
+#pragma unroll
+      for (int o = 0; o < OH; ++o) {
+        f32x4* dst = sm4 + ((size_t)(o * PW + pc) * 2) * CVB + cv;
+        dst[0] = f32x4{acc[o][0], acc[o][1], acc[o][2], acc[o][3]};
+        dst[CVB] = f32x4{acc[o][4], acc[o][5], acc[o][6], acc[o][7]};
+      }
+    } else {
+      // edge tiles (clamped starts, rows past Ho): one output row at a time, its TY source rows fetched directly
+#pragma unroll 1
+      for (int o = 0; o < OH; ++o) {
+        const int oy = min(oy0 + o, Ho - 1);
+        const int y0r = sy[oy];
+        float acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int t = 0; t < TY; ++t) {
+          float v[8];
+          load8(col + (size_t)min(y0r + t, H - 1) * W * C, v);
+          const float w = wy[oy * TY + t];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[i] += w * v[i];
+        }
+        f32x4* dst = sm4 + ((size_t)(o * PW + pc) * 2) * CVB + cv;
+        dst[0] = f32x4{acc[0], acc[1], acc[2], acc[3]};
+        dst[CVB] = f32x4{acc[4], acc[5], acc[6], acc[7]};
+      }
     }
   }
   __syncthreads();

@@ -49,7 +49,10 @@ class MappingNetwork(nn.Module):
     def _get_style_vector(self, batch_size, n_gen_blocks, device, *, mix_styles=True):
         if mix_styles and torch.rand(()).lt(self.style_mixing_prob):
             cut = int(torch.randint(0, n_gen_blocks, ()))
-            first, second = self._sample(batch_size, device), self._sample(batch_size, device)
+            # the two latents of a mixed style through the MLP as ONE 2B-row pass (same draws, in the reference's
+            # order; every row of the MLP is independent): half the tiny launches of this path
+            z = torch.cat((torch.randn(batch_size, self.d_latent), torch.randn(batch_size, self.d_latent)), 0)
+            first, second = self.forward(z.to(device)).split(batch_size, 0)
             return torch.cat((first.expand(cut, -1, -1), second.expand(n_gen_blocks - cut, -1, -1)), 0)
         return self._sample(batch_size, device).expand(n_gen_blocks, -1, -1)
 

@@ -680,7 +680,7 @@ class _ConvFn(torch.autograd.Function):
             # A bias ahead of InstanceNorm is mathematically dead: the incoming gradient (InstanceNorm's
             # backward) has zero mean over the pixels of every (sample, channel), so its sum is exactly 0
             # -- the reference's value there is rounding noise.  No reduction pass.
-            g_bias = torch.zeros(prep.co, dtype=weight.dtype, device=dev)
+            g_bias = None  # (no gradient = the zero the optimiser's zero_grad left in place)
         elif ctx.has_bias and need_b:
             if act == H.ACT_NONE and d is None:  # reduce-only pass over g (one read, nothing stored)
                 H.act_bwd_reduce(g, None, None, None, None, sums, H.ACT_NONE)

@@ -425,8 +425,12 @@ _reg("steps256", case_steps, nc=3, size=(256, 256), batch=2)     # north-star sh
 # probes of this 36 M-parameter generator mostly measure which way the noise-level gradients happened to
 # round (fp32 mode 6.6e-2, bf16 0.49 on probe/img -- measured); at 2e-5 they test the step itself.
 _reg("steps128", case_steps, nc=3, size=(128, 128), batch=2, min_latent=16, lr=2e-5)
+# ... and the same two steps at the STOCK learning rate (config.toml: 2e-3), so that config #4's topology is also
+# held to the reference on updates of the real size: the logged losses of both steps are compared at the usual
+# bounds; the post-step probes get the bounds measured for this case (tests/test_hip_parity.py::PROBE_TOL).
+_reg("steps128_stock", case_steps, nc=3, size=(128, 128), batch=2, min_latent=16, lr=2e-3)
 
-SLOW_CASES = {"steps256", "steps128"}
+SLOW_CASES = {"steps256", "steps128", "steps128_stock"}
 
 
 def run_case(name, ns, device):

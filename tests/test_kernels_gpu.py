@@ -713,3 +713,30 @@ def test_phase_pipelined_weight_gradient_matches_torch(reflect):
         # every tap and channel block individually (a mis-staged region would hide in the norm of the whole)
         per_tap = ((dw - ref) ** 2).sum(dim=(0, 3)).sqrt() / (ref ** 2).sum(dim=(0, 3)).sqrt()
         assert float(per_tap.max()) < 5e-5, per_tap
+
+
+def test_tensors_beyond_2_gib_run_as_batch_slices():
+    """fp32 parity mode at config #4 sizes: an input of exactly 2 GiB (16 x 512 x 512 x 128 floats) used to be rejected
+    (buffer descriptors address < 2 GiB).  The launchers now cut the batch into slices; a smaller-shaped stand-in with
+    the same byte count (fp32, 16 x 256 x 256 x 512 is 2 GiB too) against the same call made per 8-sample half."""
+    from one_to_many_gan_amd import _hip as H
+
+    torch.manual_seed(3)
+    B, S, Ci, Co = 16, 256, 512, 8
+    x = torch.randn(B, S, S, Ci, device="cuda")  # 2 GiB
+    assert x.numel() * 4 > 0x7fffffff
+    w = torch.randn(Co, 1, 1, Ci, device="cuda") / Ci ** 0.5
+    y = torch.empty(B, S, S, Co, device="cuda")
+    H.conv2d_fwd(x, w, y, pad=0, pad_mode=H.PAD_ZERO, act=H.ACT_RELU)
+    halves = torch.empty_like(y)
+    for b0 in (0, 8):
+        H.conv2d_fwd(x[b0:b0 + 8], w, halves[b0:b0 + 8], pad=0, pad_mode=H.PAD_ZERO, act=H.ACT_RELU)
+    torch.cuda.synchronize()
+    assert torch.equal(y, halves)
+    g = torch.randn(B, S, S, Co, device="cuda")
+    dw, dw2 = torch.zeros(Co, 1, 1, Ci, device="cuda"), torch.zeros(Co, 1, 1, Ci, device="cuda")
+    H.conv2d_wgrad(x, g, dw, pad=0, pad_mode=H.PAD_ZERO)
+    for b0 in (0, 8):
+        H.conv2d_wgrad(x[b0:b0 + 8], g[b0:b0 + 8], dw2, pad=0, pad_mode=H.PAD_ZERO)
+    torch.cuda.synchronize()
+    assert torch.equal(dw, dw2)
