@@ -739,4 +739,5 @@ def test_tensors_beyond_2_gib_run_as_batch_slices():
     for b0 in (0, 8):
         H.conv2d_wgrad(x[b0:b0 + 8], g[b0:b0 + 8], dw2, pad=0, pad_mode=H.PAD_ZERO)
     torch.cuda.synchronize()
-    assert torch.equal(dw, dw2)
+    # (the launcher cuts 15 + 1 samples, the loop 8 + 8: the pixel slices differ, so the sums agree to rounding)
+    assert float((dw - dw2).norm() / dw2.norm()) < 1e-5
