@@ -162,6 +162,25 @@ int o2m_prepare_weights(const float* w, float* full, void* w_f, void* w_d, float
                         int32_t Co, int32_t Ci, int32_t KK, int32_t Cop, int32_t Cip, float c,
                         int32_t dtype, void* stream);
 
+/* The same for EVERY filter of a network in one launch (54 launches per step otherwise).  `jobs` is a DEVICE array
+ * the caller builds once per network (the pointers are stable: parameters live in one flat bucket, the outputs are
+ * per-layer buffers reused every step); job j owns blocks [first_block, next job's first_block) of 256 threads,
+ * ceil(Cop * Cip / 256) of them; total_blocks = their sum.  `dtype` = element type of every w_f / w_d. */
+typedef struct o2m_prep_job {
+  const float* w;  /* [Co][Ci][KK] parameter                      */
+  float* full;     /* [Cop][KK][Cip] fp32 W*c                     */
+  void* w_f;       /* [Cop][KK][Cip] `dtype`                      */
+  void* w_d;       /* [Cip][KK][Cop] `dtype`, taps reversed       */
+  float* q;        /* [Cop][Cip] or NULL                          */
+  float* qt;       /* [Cip][Cop] or NULL (with q)                 */
+  int32_t Co, Ci, KK, Cop, Cip;
+  float c;
+  int32_t first_block;
+  int32_t reserved;
+} o2m_prep_job;
+int o2m_prepare_weights_batched(const o2m_prep_job* jobs, int32_t n_jobs, int32_t total_blocks, int32_t dtype,
+                                void* stream);
+
 /* Per-sample pre-modulated filters for the forward modulated conv:
  *   out[b][o][kh][kw][i] = (dtype) ( w32[o][kh][kw][i] * s[b][i] )
  * i.e. layers.py:152-154 (weights * s) without the demodulation, which stays an epilogue

@@ -47,6 +47,14 @@ class ConvDesc(C.Structure):
                 ("deq_scale", _vp), ("aux", _vp), ("aux_scaled", _vp)]
 
 
+class PrepJob(C.Structure):
+    """o2m_prep_job (include/o2m_hip.h)."""
+
+    _fields_ = [("w", _vp), ("full", _vp), ("w_f", _vp), ("w_d", _vp), ("q", _vp), ("qt", _vp),
+                ("Co", _i32), ("Ci", _i32), ("KK", _i32), ("Cop", _i32), ("Cip", _i32), ("c", _f32),
+                ("first_block", _i32), ("reserved", _i32)]
+
+
 class WgradDesc(C.Structure):
     _fields_ = [("x", _vp), ("gy", _vp), ("dw", _vp), ("in_scale", _vp), ("gy_scale", _vp),
                 ("B", _i32), ("H", _i32), ("W", _i32), ("Ci", _i32), ("Co", _i32), ("KH", _i32),
@@ -75,6 +83,7 @@ SIGNATURES = {
     "o2m_act_bwd_reduce": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "o2m_prepare_weights": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, C.c_float,
                                    _i32, _vp]),
+    "o2m_prepare_weights_batched": (_i32, [_vp, _i32, _i32, _i32, _vp]),
     "o2m_modulate_weights": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "o2m_fold_scale_dot": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32,
                                   _vp, _vp]),
@@ -296,6 +305,11 @@ def wgrad_finalize(acc, gq, w32, grad, co, ci, c):
 def prepare_weights(w, full, w_f, w_d, q, qt, c):
     """W*c in the kernel layouts (see o2m_prepare_weights); ``w`` is the raw (Co,Ci,KH,KW) parameter."""
     ops().prepare_weights(w, full, w_f, w_d, q, qt, c)
+
+
+def prepare_weights_batched(jobs, n_jobs, total_blocks, dtype, outs):
+    """Every filter of a network in one launch; ``jobs``: uint8 device tensor of PrepJob records."""
+    ops().prepare_weights_batched(jobs, n_jobs, total_blocks, dtype_code(dtype), outs)
 
 
 def modulate_weights(w32, s, out):

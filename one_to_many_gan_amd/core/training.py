@@ -91,6 +91,8 @@ def discriminator_step(config, device, discriminator, generator, mapping_network
     exactly like the reference (training.py:71-128)."""
     batch = config["training"]["batch_size"]
     discriminator_optimiser.zero_grad()
+    for net in (generator, discriminator):
+        ops.prepare_network(net)  # every stale filter of a network in one launch
 
     shoeprints = next(shoeprint_iter).to(device)
     with torch.no_grad():
@@ -210,6 +212,8 @@ def generator_step(config, device, generator, discriminator, mapping_network, st
     blocks = generator.n_style_blocks
     for opt in (generator_optimiser, mapping_network_optimiser, style_extractor_optimiser):
         opt.zero_grad()
+    for net in (generator, discriminator, style_extractor):
+        ops.prepare_network(net)  # every stale filter of a network in one launch
 
     shoeprints = next(shoeprint_iter).to(device)
     shoemarks = next(shoemark_iter).to(device)

@@ -792,6 +792,35 @@ __global__ __launch_bounds__(NT) void prepare_weights_kernel(const float* w, flo
   }
 }
 
+// Every filter of a network in ONE launch (o2m_prepare_weights_batched): block -> job by a scan of the (short)
+// table, then prepare_weights_kernel's per-(o, i) walk.
+template <typename T>
+__global__ __launch_bounds__(NT) void prepare_weights_batched_kernel(const o2m_prep_job* __restrict__ jobs, int n_jobs) {
+  int j = 0;
+  while (j + 1 < n_jobs && (int)blockIdx.x >= jobs[j + 1].first_block) ++j;  // uniform
+  const o2m_prep_job jb = jobs[j];
+  const int t = ((int)blockIdx.x - jb.first_block) * NT + threadIdx.x;
+  if (t >= jb.Cop * jb.Cip) return;
+  const int i = t % jb.Cip, o = t / jb.Cip;
+  const bool valid = o < jb.Co && i < jb.Ci;
+  const float* src = jb.w + ((size_t)o * jb.Ci + i) * jb.KK;
+  T* w_f = static_cast<T*>(jb.w_f);
+  T* w_d = static_cast<T*>(jb.w_d);
+  float acc = 0.f;
+  for (int kk = 0; kk < jb.KK; ++kk) {
+    const float v = valid ? src[kk] * jb.c : 0.f;
+    const size_t f = ((size_t)o * jb.KK + kk) * jb.Cip + i;
+    jb.full[f] = v;
+    Elem<T>::st(w_f + f, v);
+    Elem<T>::st(w_d + ((size_t)i * jb.KK + (jb.KK - 1 - kk)) * jb.Cop + o, v);
+    acc += v * v;
+  }
+  if (jb.q) {
+    jb.q[(size_t)o * jb.Cip + i] = acc;
+    jb.qt[(size_t)i * jb.Cop + o] = acc;
+  }
+}
+
 // ---- weight-gradient finalisation ----------------------------------------------------------
 // grad[o][i][kh][kw] += c * ( acc[o][kh][kw][i] + 2 * gq[o][i] * w32[o][kh][kw][i] ), then the
 // accumulators are cleared for the next backward pass.  acc is the kernel-layout fp32 buffer
@@ -1034,6 +1063,16 @@ int o2m_prepare_weights(const float* w, float* full, void* w_f, void* w_d, float
   hipStream_t s = static_cast<hipStream_t>(stream);
   DISPATCH_T(dtype, hipLaunchKernelGGL(prepare_weights_kernel<T>, dim3(grid_for((long)Cop * Cip)), dim3(NT),
                                        0, s, w, full, (T*)w_f, (T*)w_d, q, qt, Co, Ci, KK, Cop, Cip, c));
+  O2M_LAUNCH_CHECK();
+  return 0;
+}
+
+int o2m_prepare_weights_batched(const o2m_prep_job* jobs, int32_t n_jobs, int32_t total_blocks, int32_t dtype,
+                                void* stream) {
+  if (!jobs || n_jobs <= 0 || total_blocks <= 0) return O2M_ERR_BAD_ARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(prepare_weights_batched_kernel<T>, dim3((unsigned)total_blocks), dim3(NT), 0, s,
+                                       jobs, n_jobs));
   O2M_LAUNCH_CHECK();
   return 0;
 }

@@ -244,6 +244,16 @@ void prepare_weights(const Tensor& w, Tensor& full, Tensor& w_f, Tensor& w_d, co
                                      static_cast<float>(c), dt_w_f, stream));
 }
 
+void prepare_weights_batched(const Tensor& jobs, int64_t n_jobs, int64_t total_blocks, int64_t dtype, at::TensorList outs) {
+  const char* op = "o2m::prepare_weights_batched";
+  chk(jobs, op, "jobs");
+  TORCH_CHECK(jobs.scalar_type() == at::kByte && jobs.numel() >= n_jobs * static_cast<int64_t>(sizeof(o2m_prep_job)), op,
+              ": jobs is a uint8 device tensor of n_jobs o2m_prep_job records");
+  for (const Tensor& t : outs) chk(t, op, "outs[]");  // the buffers the records point at (kept alive / declared mutated)
+  O2M_CALL(op, jobs, o2m_prepare_weights_batched(static_cast<const o2m_prep_job*>(ptr(jobs)), i32(n_jobs, op), i32(total_blocks, op),
+                                                i32(dtype, op), stream));
+}
+
 void amax(const Tensor& x, Tensor& out) {
   const char* op = "o2m::amax";
   chk(x, op, "x"); chk_f32(out, op, "amax");
@@ -558,6 +568,7 @@ TORCH_LIBRARY(o2m, m) {
   m.def("conv2d_wgrad_slab_floats(Tensor x, Tensor gy, Tensor dw, int pad, int pad_mode, int splits, int n_more, int stride) -> int");
   m.def("wgrad_finalize(Tensor(a!) acc, Tensor(b!)? gq, Tensor w32, Tensor(c!) grad, int co, int ci, float c) -> ()");
   m.def("prepare_weights(Tensor w, Tensor(a!) full, Tensor(b!) w_f, Tensor(c!) w_d, Tensor(d!)? q, Tensor(e!)? qt, float c) -> ()");
+  m.def("prepare_weights_batched(Tensor jobs, int n_jobs, int total_blocks, int dtype, Tensor(a!)[] outs) -> ()");
   m.def("modulate_weights(Tensor w32, Tensor s, Tensor(a!) out) -> ()");
   m.def("style_fwd(Tensor w, Tensor ws, Tensor bs, Tensor? qt, Tensor(a!) s, Tensor(b!)? d, int ci, float cs, float eps) -> ()");
   m.def("style_bwd(Tensor? sums, Tensor? bias, Tensor? dots, Tensor s, Tensor? d, Tensor? q, Tensor w, Tensor ws, Tensor(a!)? e, "
@@ -591,6 +602,7 @@ TORCH_LIBRARY(o2m, m) {
   m.impl("conv2d_wgrad_slab_floats", &conv2d_wgrad_slab_floats); \
   m.impl("wgrad_finalize", &wgrad_finalize);      \
   m.impl("prepare_weights", &prepare_weights);    \
+  m.impl("prepare_weights_batched", &prepare_weights_batched); \
   m.impl("modulate_weights", &modulate_weights);  \
   m.impl("amax", &amax);                          \
   m.impl("quantize_fp8", &quantize_fp8);          \

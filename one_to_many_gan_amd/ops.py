@@ -68,9 +68,55 @@ def compute_dtype() -> torch.dtype:
     return _STATE["dtype"]
 
 
-def bump_weights_epoch() -> None:
-    """Called by optimisers that update parameters behind autograd's back (fused Adam)."""
-    _STATE["epoch"] += 1
+def bump_weights_epoch(params=None) -> None:
+    """Called by optimisers that update parameters behind autograd's back (fused Adam): ``params`` = the
+    parameters just written (None: every cached filter form is stale)."""
+    if params is None:
+        _STATE["epoch"] += 1
+        return
+    for p in params:
+        p._o2m_epoch = getattr(p, "_o2m_epoch", 0) + 1
+
+
+def weights_epoch(p) -> tuple:
+    return (_STATE["epoch"], getattr(p, "_o2m_epoch", 0))
+
+
+_NET_JOBS: dict = {}
+
+
+def prepare_network(module) -> None:
+    """The kernel-side forms of EVERY filter of ``module`` in one launch (o2m_prepare_weights_batched) when all of
+    them are stale -- the state right after the network's optimiser step -- instead of one launch per layer on
+    first use (54 launches per D+G step at 256 x 256).  Anything unusual (some layers fresh, parameters not fp32 /
+    contiguous) is left to the per-layer path of PreparedWeight.get()."""
+    import ctypes
+
+    preps = [m._prepared() for m in module.modules() if hasattr(m, "_prepared")]
+    if not preps or not preps[0].weight.is_cuda:
+        return
+    keys = [p.version_key() for p in preps]
+    if any(k == p._key for k, p in zip(keys, preps)):
+        return  # (partly) fresh: the lazy path prepares what is left
+    if any(p.weight.dtype != torch.float32 or not p.weight.is_contiguous() for p in preps):
+        return
+    bufs = [p.buffers() for p in preps]
+    ident = tuple((p.weight.data_ptr(), b[3].data_ptr()) for p, b in zip(preps, bufs)) + (compute_dtype(),)
+    hit = _NET_JOBS.get(id(module))
+    if hit is None or hit[0] != ident:
+        jobs, first = (H.PrepJob * len(preps))(), 0
+        for j, (p, (w_f, w_d, q, full, qt)) in enumerate(zip(preps, bufs)):
+            jobs[j] = H.PrepJob(p.weight.data_ptr(), full.data_ptr(), w_f.data_ptr(), w_d.data_ptr(),
+                                q.data_ptr() if q is not None else None, qt.data_ptr() if qt is not None else None,
+                                p.co, p.ci, p.kh * p.kw, p.cop, p.cip, p.c, first, 0)
+            first += (p.cop * p.cip + 255) // 256
+        raw = torch.frombuffer(bytearray(ctypes.string_at(ctypes.addressof(jobs), ctypes.sizeof(jobs))), dtype=torch.uint8)
+        hit = _NET_JOBS[id(module)] = (ident, raw.to(preps[0].weight.device), len(preps), first)
+    outs = [t for b in bufs for t in b if t is not None]
+    with torch.no_grad():
+        H.prepare_weights_batched(hit[1], hit[2], hit[3], compute_dtype(), outs)
+    for p, k, b in zip(preps, keys, bufs):
+        p._val, p._key = b, k
 
 
 def pad8(c: int) -> int:
@@ -239,7 +285,7 @@ class PreparedWeight:
                 and pad_mode == H.PAD_REFLECT and hh % r == 0 and ww % r == 0 and self.ci % 64 == 0)
 
     def s2d_weights(self):
-        key = (self.weight._version, self.weight.data_ptr(), _STATE["epoch"], compute_dtype())
+        key = self.version_key()
         if getattr(self, "_s2d_key", None) != key:
             full = self.get()[3]  # [cop, kh, kw, cip] fp32, W*c
             r, k = self.S2D, self.kh
@@ -284,19 +330,36 @@ class PreparedWeight:
         sco = kk * kk * self.cip
         return w2.as_strided((r, r, self.co, k, k, self.cip), (r * self.co * sco + sa, self.co * sco + sb, sco, sa, sb, 1))
 
-    def get(self):
+    def version_key(self):
+        """Changes when the kernel-side forms are stale: the parameter was written through autograd's version
+        counter, re-homed, updated by its fused optimiser (``weights_epoch`` of its bucket -- per network, so a
+        step of the discriminator's optimiser does not invalidate the generator's filters) or the precision mode
+        changed."""
         w = self.weight
-        key = (w._version, w.data_ptr(), _STATE["epoch"], compute_dtype())
+        return (w._version, w.data_ptr(), weights_epoch(w), compute_dtype())
+
+    def buffers(self):
+        """The per-layer output buffers, allocated once per (device, dtype) and refilled in place: stable addresses
+        are what lets one batched launch serve a whole network (prepare_network).  Every stream that reads them has
+        been joined with the main one by the end of the previous backward pass (_finalize_weight_grads)."""
+        dev, cd = self.weight.device, compute_dtype()
+        if getattr(self, "_buf_key", None) != (dev, cd):
+            full = torch.empty((self.cop, self.kh, self.kw, self.cip), dtype=torch.float32, device=dev)
+            w_f = torch.empty((self.cop, self.kh, self.kw, self.cip), dtype=cd, device=dev)
+            w_d = torch.empty((self.cip, self.kh, self.kw, self.cop), dtype=cd, device=dev)
+            q = torch.empty((self.cop, self.cip), dtype=torch.float32, device=dev) if self.need_q else None
+            qt = torch.empty((self.cip, self.cop), dtype=torch.float32, device=dev) if self.need_q else None
+            self._bufs, self._buf_key = (w_f, w_d, q, full, qt), (dev, cd)
+            self._key = None
+        return self._bufs
+
+    def get(self):
+        key = self.version_key()
         if key != self._key:
             with torch.no_grad():
-                wsrc = w.detach().float().contiguous()  # no-ops for the fp32 parameters
-                dev, cd = w.device, compute_dtype()
-                full = torch.empty((self.cop, self.kh, self.kw, self.cip), dtype=torch.float32, device=dev)
-                w_f = torch.empty((self.cop, self.kh, self.kw, self.cip), dtype=cd, device=dev)
-                w_d = torch.empty((self.cip, self.kh, self.kw, self.cop), dtype=cd, device=dev)
-                q = torch.empty((self.cop, self.cip), dtype=torch.float32, device=dev) if self.need_q else None
-                qt = torch.empty((self.cip, self.cop), dtype=torch.float32, device=dev) if self.need_q else None
-                H.prepare_weights(wsrc, full, w_f, w_d, q, qt, self.c)  # one launch per layer and step
+                wsrc = self.weight.detach().float().contiguous()  # no-ops for the fp32 parameters
+                w_f, w_d, q, full, qt = self.buffers()
+                H.prepare_weights(wsrc, full, w_f, w_d, q, qt, self.c)  # one launch for this layer
             self._val = (w_f, w_d, q, full, qt)
             self._key = key
         return self._val

@@ -75,7 +75,7 @@ class FusedAdam:
         self.step_t += 1
         H.adam_step(self.bucket.flat, self.bucket.grad, self.exp_avg, self.exp_avg_sq, self.step_t,
                     self.lr, self.betas[0], self.betas[1], self.eps, self.grad_scale)
-        ops.bump_weights_epoch()
+        ops.bump_weights_epoch(self.bucket.params)  # this network's cached filter forms are stale, nobody else's
 
     def state_dict(self):
         """``torch.optim.Adam.state_dict()`` layout (what the reference checkpoints,

@@ -741,3 +741,33 @@ def test_tensors_beyond_2_gib_run_as_batch_slices():
     torch.cuda.synchronize()
     # (the launcher cuts 15 + 1 samples, the loop 8 + 8: the pixel slices differ, so the sums agree to rounding)
     assert float((dw - dw2).norm() / dw2.norm()) < 1e-5
+
+
+def test_batched_weight_preparation_equals_the_per_layer_launches():
+    """ops.prepare_network: every filter of a network in ONE launch (o2m_prepare_weights_batched) against the
+    per-layer o2m_prepare_weights launches, bit for bit, plain and modulated layers, padded channel counts."""
+    import one_to_many_gan_amd as pk
+    from one_to_many_gan_amd import ops
+    from one_to_many_gan_amd.model import builder
+
+    for precision in ("bf16", "fp32"):
+        pk.set_precision(precision)
+        torch.manual_seed(4)
+        net = builder.Generator(3, 6, (32, 32), 8, 3, start_filters=8).cuda()
+        preps = [m._prepared() for m in net.modules() if hasattr(m, "_prepared")]
+        assert len(preps) >= 8
+        want = [[None if t is None else t.clone() for t in p.get()] for p in preps]  # per-layer path
+        ops.bump_weights_epoch([p.weight for p in preps])
+        for p in preps:  # poison the buffers: the batched launch must rewrite every element
+            for t in p.buffers():
+                if t is not None:
+                    t.fill_(float("nan"))
+        ops.prepare_network(net)
+        torch.cuda.synchronize()
+        for p, w in zip(preps, want):
+            assert p._key == p.version_key(), "marked fresh"
+            for a, b in zip(p.get(), w):
+                assert (a is None) == (b is None)
+                if a is not None:
+                    assert torch.equal(a, b)
+    pk.set_precision("bf16")
