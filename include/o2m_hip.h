@@ -231,7 +231,11 @@ typedef struct {
                             Wo % 32 == 0 and no in_scale / gy_scale. */
   int32_t stride;        /* 0/1: unit stride; >1: gy is the output of a strided conv
                             (Ho = (H + 2 pad - KH) / stride + 1)                          */
-  int32_t reserved[1];
+  int32_t kernel_hint;   /* 0: the register-staged tiles.  O2M_WGRAD_HINT_P8 (1): the phase-pipelined 256 x 256
+                            kernel (LDS-DMA fills, transposing LDS reads) where it applies -- Co = Ci = 256, 3 x 3, pad 1,
+                            64-pixel rows, bf16, slab mode -- else as 0.  Alone on the chip it is 1.1-1.3x faster; it
+                            holds a whole CU per block (128 KB of LDS), so beside another stream's kernels the smaller
+                            tiles pack better: the caller chooses. */
   float* slabs;          /* NULL: the pixel slices add into dw with fp32 atomics (arrival order: the last
                             bits differ from run to run).  Otherwise a workspace of
                             o2m_conv2d_wgrad_slab_floats(d) floats: every slice STORES its Co x K partial
@@ -241,6 +245,7 @@ typedef struct {
   const void* x_seg[8];  /* [0] ignored (= x)  */
   const void* gy_seg[8]; /* [0] ignored (= gy) */
 } o2m_wgrad_desc;
+#define O2M_WGRAD_HINT_P8 1
 int o2m_conv2d_wgrad(const o2m_wgrad_desc* d, void* stream);
 /* Floats of slab workspace o2m_conv2d_wgrad needs for this problem (0 for an invalid descriptor). */
 size_t o2m_conv2d_wgrad_slab_floats(const o2m_wgrad_desc* d);

@@ -598,8 +598,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_p8_kernel(const o2m_wgrad_d
 
 // the layers the phase-pipelined weight-gradient kernel takes; *splits / *rows: its slicing of the image rows
 inline bool wgrad_p8_ok(const o2m_wgrad_desc& d, long* splits, long* rows) {
-  static const int on = [] { const char* e = getenv("O2M_WGRAD_P8"); return e ? atoi(e) : 1; }();
-  if (!on || d.dtype != O2M_BF16 || d.Co != 256 || d.Ci != 256 || d.KH != 3 || d.KW != 3 || d.pad != 1 || d.stride > 1 ||
+  if (d.kernel_hint != O2M_WGRAD_HINT_P8 || d.dtype != O2M_BF16 || d.Co != 256 || d.Ci != 256 || d.KH != 3 || d.KW != 3 || d.pad != 1 || d.stride > 1 ||
       d.W != 64 || d.in_scale || d.gy_scale || d.nseg > 1 || d.splits > 0)
     return false;
   const long r_total = (long)d.B * d.H;

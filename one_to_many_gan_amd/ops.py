@@ -403,6 +403,21 @@ def _early_finalize() -> bool:
 _WSTREAM: dict = {}
 
 
+# The phase-pipelined weight-gradient kernel (o2m_wgrad_desc.kernel_hint) holds a whole CU per block: alone on the
+# chip it is 1.1-1.3x faster than the register-staged tiles (B = 16 / 32 / 48: 767 / 877 / 915 vs 580 / 700 / 826
+# TFLOP/s on the 256 -> 256 layers), but on the weight-gradient stream BESIDE the main stream it keeps the HBM-bound
+# kernels of the following layers off the CUs for its whole run, and the step loses 0.3-0.4 ms (four same-box A/B
+# runs, profiles/README.md).  Default: used exactly when the weight gradient runs in-line on the main stream
+# (O2M_WGRAD_STREAM=0); O2M_WGRAD_P8=1 / 0 forces it.
+_WGRAD_P8 = _os.environ.get("O2M_WGRAD_P8")
+
+
+def _wgrad_p8(wst) -> bool:
+    if _WGRAD_P8 is not None:
+        return _WGRAD_P8 == "1"
+    return wst is None
+
+
 def _wgrad_stream(device):
     if not _WGRAD_STREAM or device.type != "cuda":
         return None
@@ -862,9 +877,9 @@ class _ConvFn(torch.autograd.Function):
                 if s is None and residual is None and prep.s2d_ok(pad, pad_mode, Hh, Ww):
                     prep.s2d_wgrad(x, gu, pad, pad_mode)
                 elif xs is not None:
-                    H.conv2d_wgrad(xs, gu, dw_acc, pad=pad, pad_mode=pad_mode)
+                    H.conv2d_wgrad(xs, gu, dw_acc, pad=pad, pad_mode=pad_mode, p8=_wgrad_p8(wst))
                 else:  # plain conv (s None), or the modulated input formed while x is staged (in_scale)
-                    H.conv2d_wgrad(x, gu, dw_acc, in_scale=s, pad=pad, pad_mode=pad_mode)
+                    H.conv2d_wgrad(x, gu, dw_acc, in_scale=s, pad=pad, pad_mode=pad_mode, p8=_wgrad_p8(wst))
 
         if need_w and not defer_fold:
             launch_wgrad()

@@ -699,7 +699,7 @@ def test_phase_pipelined_weight_gradient_matches_torch(reflect):
         pm = H.PAD_REFLECT if reflect else H.PAD_ZERO
         H.launch_timing(True)
         try:
-            H.conv2d_wgrad(x, g, dw, pad=1, pad_mode=pm)
+            H.conv2d_wgrad(x, g, dw, pad=1, pad_mode=pm, p8=True)
             torch.cuda.synchronize()
             names = set(H.launch_timing_read())
         finally:

@@ -61,7 +61,7 @@ def main():
       if which in ("all", "wgrad"):
           gy = torch.randn(B, ho, wo, Co, device=dev).to(dt)
           dw = torch.zeros(Co, k, k, Ci, device=dev)
-          t = timeit(lambda: H.conv2d_wgrad(x, gy, dw, pad=pad, pad_mode=pm))
+          t = timeit(lambda: H.conv2d_wgrad(x, gy, dw, pad=pad, pad_mode=pm, p8=os.environ.get('O2M_WGRAD_P8', '1') == '1'))
           line += f"wgrad {t*1e6:8.1f} us {flops/t/1e12:7.1f} TF/s"
       print(line, flush=True)
 

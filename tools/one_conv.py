@@ -18,5 +18,5 @@ for _ in range(5):
     if mode == "fwd":
         H.conv2d_fwd(x, w, y, pad=pad, pad_mode=pm, act=H.ACT_RELU)
     else:
-        H.conv2d_wgrad(x, gy, dw, pad=pad, pad_mode=pm)
+        H.conv2d_wgrad(x, gy, dw, pad=pad, pad_mode=pm, p8=True)
 torch.cuda.synchronize()
