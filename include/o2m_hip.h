@@ -327,6 +327,24 @@ int o2m_instnorm_bwd(const void* g, const void* x, const float* mean_rstd, float
                      float* gsums, void* gx, int32_t B, int32_t P, int32_t C, int32_t act,
                      int32_t dtype, void* stream);
 
+/* InstanceNorm + activation + DownSample in one pass, and its backward (builder.py:170-173,272-282: conv ->
+ * InstanceNorm2d -> ReLU / LeakyReLU -> DownSample in the encoder and in the discriminator / style-extractor trunk).
+ *   fwd: y = D( act( (x - mean) * rstd ) ), D = the banded operator (sy, wy, sx, wx) of o2m_resample2d below with T = 4
+ *        taps per axis and starts 2 or 3 apart (DownSample on even / odd sizes); O2M_ERR_UNSUPPORTED for any other
+ *        operator (the caller runs o2m_instnorm_apply + o2m_resample2d).  The normalised map is never stored.
+ *   bwd: gx = InstanceNorm_backward( D^T g_coarse ) with the taps of the TRANSPOSED operator (T = 2 per axis): the fine
+ *        gradient D^T g is gathered per pixel in both passes (sums, apply) instead of being written once and read twice.
+ *        partial / gsums as in o2m_instnorm_bwd.  x [B][H][W][C], g_coarse [B][Hl][Wl][C].
+ */
+int o2m_instnorm_act_resample2d(const void* x, const float* mean_rstd, void* y, const int32_t* sy, const float* wy,
+                                const int32_t* sx, const float* wx, int32_t B, int32_t H, int32_t W, int32_t Ho,
+                                int32_t Wo, int32_t C, int32_t T, int32_t span_y, int32_t span_x, int32_t act,
+                                int32_t dtype, void* stream);
+int o2m_instnorm_resample_bwd(const void* g_coarse, const void* x, const float* mean_rstd, float* partial,
+                              float* gsums, void* gx, const int32_t* sy, const float* wy, const int32_t* sx,
+                              const float* wx, int32_t B, int32_t H, int32_t W, int32_t Hl, int32_t Wl, int32_t C,
+                              int32_t T, int32_t act, int32_t dtype, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Separable banded resampling: y[b,oy,ox,c] = sum_{ty,tx} wy[oy,ty]*wx[ox,tx] *
  *                                             x[b, sy[oy]+ty, sx[ox]+tx, c]

@@ -91,6 +91,8 @@ SIGNATURES = {
     "o2m_instnorm_stats": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp]),
     "o2m_instnorm_apply": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "o2m_instnorm_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "o2m_instnorm_act_resample2d": (_i32, [_vp] * 7 + [_i32] * 11 + [_vp]),
+    "o2m_instnorm_resample_bwd": (_i32, [_vp] * 10 + [_i32] * 9 + [_vp]),
     "o2m_resample2d": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                               _i32, _i32, _i32, _i32, _vp]),
     "o2m_ada_grid_sample": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
@@ -347,6 +349,15 @@ def instnorm_apply(x, mean_rstd, residual, y, act):
 
 def instnorm_bwd(g, x, mean_rstd, partial, gsums, gx, act):
     ops().instnorm_bwd(g, x, mean_rstd, partial, gsums, gx, act)
+
+
+def instnorm_act_resample2d(x, mean_rstd, y, sy, wy, sx, wx, t, span_y, span_x, act):
+    """y = D(act(InstanceNorm(x))) for the DownSample operators (t == 4, spans 2 or 3)."""
+    ops().instnorm_act_resample2d(x, mean_rstd, y, sy, wy, sx, wx, t, span_y, span_x, act)
+
+
+def instnorm_resample_bwd(g_coarse, x, mean_rstd, partial, gsums, gx, sy, wy, sx, wx, t, act):
+    ops().instnorm_resample_bwd(g_coarse, x, mean_rstd, partial, gsums, gx, sy, wy, sx, wx, t, act)
 
 
 def resample2d(x, y, sy, wy, sx, wx, ty, tx=None, span_y=0, span_x=0):

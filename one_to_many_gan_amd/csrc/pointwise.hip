@@ -235,11 +235,41 @@ __global__ __launch_bounds__(NT) void chunk_sum3_kernel(float* __restrict__ dots
 
 // ---- instance norm ---------------------------------------------------------------------------
 // MODE 0: {sum x, sum x^2};  MODE 1 (backward): {sum gh, sum gh*xh}
-template <typename T, int MODE>
+// Banded operator applied to the incoming gradient on the fly (InstanceNorm backward behind a DownSample: the
+// gradient of the normalised map is the TRANSPOSED down-sampling of the low-resolution gradient, two taps per axis;
+// it is gathered per pixel instead of being stored and read twice).
+struct GatherTaps {
+  const int* sy;
+  const float* wy;
+  const int* sx;
+  const float* wx;
+  int W, Hl, Wl;  // width of the fine map; size of the coarse gradient
+};
+template <typename T, int TG>
+__device__ __forceinline__ void gather_grad(const T* __restrict__ gl, const GatherTaps& tp, int b, int yy, int xx, int C,
+                                            int cv, float (&gv)[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) gv[i] = 0.f;
+  const int y0 = tp.sy[yy], x0 = tp.sx[xx];
+#pragma unroll
+  for (int ty = 0; ty < TG; ++ty) {
+    const float a = tp.wy[yy * TG + ty];
+#pragma unroll
+    for (int tx = 0; tx < TG; ++tx) {
+      const float w = a * tp.wx[xx * TG + tx];
+      float v[8];
+      load8(gl + (((size_t)b * tp.Hl + min(y0 + ty, tp.Hl - 1)) * tp.Wl + min(x0 + tx, tp.Wl - 1)) * C + cv * 8, v);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) gv[i] += w * v[i];
+    }
+  }
+}
+
+template <typename T, int MODE, int TG = 0>
 __global__ __launch_bounds__(NT) void in_partial_kernel(const T* __restrict__ x, const T* __restrict__ g,
                                                         const float* __restrict__ mean_rstd,
                                                         float* __restrict__ partial,
-                                                        int P, int C, int act, ChanGeom gm) {
+                                                        int P, int C, int act, ChanGeom gm, GatherTaps tp = GatherTaps{}) {
   extern __shared__ float sm[];
   const int b = blockIdx.y, ch = blockIdx.x;
   const int cv = threadIdx.x % gm.CV, pl = threadIdx.x / gm.CV;
@@ -256,6 +286,12 @@ __global__ __launch_bounds__(NT) void in_partial_kernel(const T* __restrict__ x,
     }
   }
   if (pl < gm.PL) {
+    int yy = 0, xx = 0;
+    if constexpr (TG > 0) {
+      const int p0 = ch * gm.chunk + pl;
+      yy = p0 / tp.W;
+      xx = p0 - yy * tp.W;
+    }
 #pragma unroll 4
     for (int p = ch * gm.chunk + pl; p < pe; p += gm.PL) {
       const size_t o = ((size_t)b * P + p) * C + cv * 8;
@@ -266,7 +302,13 @@ __global__ __launch_bounds__(NT) void in_partial_kernel(const T* __restrict__ x,
         for (int i = 0; i < 8; ++i) { acc[i] += xv[i]; acc[8 + i] += xv[i] * xv[i]; }
       } else {
         float gv[8];
-        load8(g + o, gv);
+        if constexpr (TG > 0) {
+          gather_grad<T, TG>(g, tp, b, yy, xx, C, cv, gv);
+          xx += gm.PL;
+          while (xx >= tp.W) { xx -= tp.W; ++yy; }
+        } else {
+          load8(g + o, gv);
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           float xh = (xv[i] - mu[i]) * rs[i];
@@ -315,12 +357,12 @@ __global__ void in_finalize_kernel(const float* partial, float* out, int B, int 
 // Same block geometry as the reductions (one pixel chunk of one sample per block, a thread keeps
 // its 8 channels): the per-(b,c) statistics sit in registers and the pixel walk needs no integer
 // division; four pixels are in flight per thread.
-template <typename T, int MODE>
+template <typename T, int MODE, int TG = 0>
 __global__ __launch_bounds__(NT) void in_apply_kernel(const T* __restrict__ x, const T* __restrict__ g,
                                                       const float* __restrict__ mean_rstd,
                                                       const float* __restrict__ gsums,
                                                       const T* __restrict__ res, T* __restrict__ out,
-                                                      int P, int C, int act, ChanGeom gm) {
+                                                      int P, int C, int act, ChanGeom gm, GatherTaps tp = GatherTaps{}) {
   const int b = blockIdx.y, ch = blockIdx.x;
   const int cv = threadIdx.x % gm.CV, pl = threadIdx.x / gm.CV;
   if (pl >= gm.PL) return;
@@ -345,8 +387,16 @@ __global__ __launch_bounds__(NT) void in_apply_kernel(const T* __restrict__ x, c
       if (p < pe) {
         const size_t o = ((size_t)b * P + p) * C + cv * 8;
         load8(x + o, xv[u]);
-        if (MODE == 1) load8(g + o, sv[u]);
-        else if (res) load8(res + o, sv[u]);
+        if (MODE == 1) {
+          if constexpr (TG > 0) {
+            const int yy = p / tp.W;
+            gather_grad<T, TG>(g, tp, b, yy, p - yy * tp.W, C, cv, sv[u]);
+          } else {
+            load8(g + o, sv[u]);
+          }
+        } else if (res) {
+          load8(res + o, sv[u]);
+        }
       }
     }
 #pragma unroll
@@ -430,19 +480,32 @@ __global__ __launch_bounds__(NT) void resample_kernel(const T* x, T* y, const in
 // drop to a quarter of the patch.  Each patch row is reduced horizontally for both output columns as it
 // arrives, then scattered into the two output rows with the vertical weights.  Grid (x, oy/2, b):
 // no 64-bit index arithmetic.
-template <typename T, int TY, int TX, int SY, int SX>
+// NORM: the operator is applied to act(InstanceNorm(x)) formed on the fly from mean_rstd ([B][C][2]) -- the
+// conv -> InstanceNorm -> (Leaky)ReLU -> DownSample chains of the encoder and of the discriminator / style extractor
+// (builder.py:170-173,272-282) without the normalised map ever being written: it is not needed by the backward
+// pass either (InstanceNorm differentiates through x and the statistics, the activation mask is the sign of xh).
+template <typename T, int TY, int TX, int SY, int SX, bool NORM = false>
 __global__ __launch_bounds__(NT) void resample2x2_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                          const int* __restrict__ sy,
                                                          const float* __restrict__ wy,
                                                          const int* __restrict__ sx,
                                                          const float* __restrict__ wx, int H, int W,
-                                                         int Ho, int Wo, int C) {
+                                                         int Ho, int Wo, int C,
+                                                         const float* __restrict__ mean_rstd = nullptr, int act = 0) {
   constexpr int PY = TY + SY, PX = TX + SX;
   const int CV = C / 8;
   const int t = blockIdx.x * NT + threadIdx.x;
   const int cv = t % CV, ox0 = (t / CV) * 2;
   const int oy0 = blockIdx.y * 2, b = blockIdx.z;
   if (ox0 >= Wo) return;
+  float mu[NORM ? 8 : 1], rs[NORM ? 8 : 1];
+  const bool relu = act == O2M_ACT_RELU;
+  const float neg = act == O2M_ACT_LRELU ? 0.2f : 1.f;
+  if constexpr (NORM) {
+    const float* mr = mean_rstd + ((size_t)b * C + cv * 8) * 2;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { mu[i] = mr[2 * i]; rs[i] = mr[2 * i + 1]; }
+  }
   const bool has_x1 = ox0 + 1 < Wo, has_y1 = oy0 + 1 < Ho;
   const int ox1 = has_x1 ? ox0 + 1 : ox0, oy1 = has_y1 ? oy0 + 1 : oy0;
   const int x0 = sx[ox0], y0 = sy[oy0];
@@ -480,6 +543,10 @@ __global__ __launch_bounds__(NT) void resample2x2_kernel(const T* __restrict__ x
       const int ix = min(x0 + k, W - 1);
       float v[8];
       load8(base + ((size_t)iy * W + ix) * C, v);
+      if constexpr (NORM) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = act_fwd_piecewise((v[i] - mu[i]) * rs[i], relu, neg);
+      }
 #pragma unroll
       for (int i = 0; i < 8; ++i) { h0[i] += cx[0][k] * v[i]; h1[i] += cx[1][k] * v[i]; }
     }
@@ -1202,6 +1269,53 @@ int o2m_instnorm_bwd(const void* g, const void* x, const float* mean_rstd, float
                        gsums, B, P, C, gm.nchunks, 0.f);
     hipLaunchKernelGGL((in_apply_kernel<T, 1>), dim3(gm.nchunks, B), dim3(NT), 0, s, (const T*)x,
                        (const T*)g, mean_rstd, gsums, (const T*)nullptr, (T*)gx, P, C, act, gm);
+  });
+  O2M_LAUNCH_CHECK();
+  return 0;
+}
+
+int o2m_instnorm_act_resample2d(const void* x, const float* mean_rstd, void* y, const int32_t* sy, const float* wy,
+                                const int32_t* sx, const float* wx, int32_t B, int32_t H, int32_t W, int32_t Ho, int32_t Wo,
+                                int32_t C, int32_t T_, int32_t span_y, int32_t span_x, int32_t act, int32_t dtype,
+                                void* stream) {
+  if (!x || !mean_rstd || !y || !sy || !wy || !sx || !wx) return O2M_ERR_BAD_ARG;
+  if (B <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || (C & 7) || act == O2M_ACT_TANH) return O2M_ERR_BAD_ARG;
+  if (T_ != 4 || span_y < 2 || span_y > 3 || span_x < 2 || span_x > 3 || B > 65535 || (Ho + 1) / 2 > 65535)
+    return O2M_ERR_UNSUPPORTED;  // the DownSample operators (4 taps, starts 2 or 3 apart); the caller falls back
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)((((long)(Wo + 1) / 2) * (C / 8) + NT - 1) / NT), (unsigned)((Ho + 1) / 2), (unsigned)B);
+#define O2M_IN_DOWN(SY, SX)                                                                                      \
+  if (span_y == SY && span_x == SX) {                                                                            \
+    DISPATCH_T(dtype, hipLaunchKernelGGL((resample2x2_kernel<T, 4, 4, SY, SX, true>), grid, dim3(NT), 0, s,      \
+                                         (const T*)x, (T*)y, sy, wy, sx, wx, H, W, Ho, Wo, C, mean_rstd, act));  \
+    O2M_LAUNCH_CHECK();                                                                                          \
+    return 0;                                                                                                    \
+  }
+  O2M_IN_DOWN(2, 2) O2M_IN_DOWN(3, 3) O2M_IN_DOWN(2, 3) O2M_IN_DOWN(3, 2)
+#undef O2M_IN_DOWN
+  return O2M_ERR_UNSUPPORTED;
+}
+
+int o2m_instnorm_resample_bwd(const void* g_coarse, const void* x, const float* mean_rstd, float* partial, float* gsums,
+                              void* gx, const int32_t* sy, const float* wy, const int32_t* sx, const float* wx,
+                              int32_t B, int32_t H, int32_t W, int32_t Hl, int32_t Wl, int32_t C, int32_t T_, int32_t act,
+                              int32_t dtype, void* stream) {
+  if (!g_coarse || !x || !mean_rstd || !partial || !gsums || !gx || !sy || !wy || !sx || !wx) return O2M_ERR_BAD_ARG;
+  if (B <= 0 || H <= 0 || W <= 0 || Hl <= 0 || Wl <= 0 || C <= 0 || (C & 7) || C > 8 * NT || act == O2M_ACT_TANH)
+    return O2M_ERR_BAD_ARG;
+  if (T_ != 2) return O2M_ERR_UNSUPPORTED;  // the transposed DownSample: two taps per axis
+  const int P = H * W;
+  ChanGeom gm = chan_geom(B, P, C);
+  const size_t lds = (size_t)gm.PL * gm.CV * 16 * sizeof(float);
+  const GatherTaps tp{sy, wy, sx, wx, W, Hl, Wl};
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  DISPATCH_T(dtype, {
+    hipLaunchKernelGGL((in_partial_kernel<T, 1, 2>), dim3(gm.nchunks, B), dim3(NT), lds, s, (const T*)x, (const T*)g_coarse,
+                       mean_rstd, partial, P, C, act, gm, tp);
+    hipLaunchKernelGGL(in_finalize_kernel<1>, dim3((B * C + 255) / 256), dim3(256), 0, s, partial, gsums, B, P, C,
+                       gm.nchunks, 0.f);
+    hipLaunchKernelGGL((in_apply_kernel<T, 1, 2>), dim3(gm.nchunks, B), dim3(NT), 0, s, (const T*)x, (const T*)g_coarse,
+                       mean_rstd, gsums, (const T*)nullptr, (T*)gx, P, C, act, gm, tp);
   });
   O2M_LAUNCH_CHECK();
   return 0;

@@ -364,6 +364,46 @@ void fold_scale_dot(const Tensor& gpad, const OptT& x, const OptT& scale, Tensor
                                      i32(gx.size(2), op), i32(gx.size(3), op), i32(pad, op), dt_gx, ptr<float>(partials), stream));
 }
 
+void instnorm_act_resample2d(const Tensor& x, const Tensor& mean_rstd, Tensor& y, const Tensor& sy, const Tensor& wy, const Tensor& sx,
+                             const Tensor& wx, int64_t t, int64_t span_y, int64_t span_x, int64_t act) {
+  const char* op = "o2m::instnorm_act_resample2d";
+  chk(x, op, "x"); chk_f32(mean_rstd, op, "mean_rstd"); chk(y, op, "y"); chk(sy, op, "sy"); chk_f32(wy, op, "wy"); chk(sx, op, "sx");
+  chk_f32(wx, op, "wx");
+  TORCH_CHECK(x.dim() == 4 && y.dim() == 4 && x.size(0) == y.size(0) && x.size(3) == y.size(3), op, ": x, y are NHWC of one batch / width");
+  same_dtype(x, y, op, "x", "y");
+  TORCH_CHECK(sy.scalar_type() == at::kInt && sx.scalar_type() == at::kInt, op, ": tap starts are int32");
+  TORCH_CHECK(sy.numel() == y.size(1) && sx.numel() == y.size(2) && wy.numel() == y.size(1) * t && wx.numel() == y.size(2) * t, op,
+              ": taps are [Ho] / [Ho][T] and [Wo] / [Wo][T]");
+  TORCH_CHECK(mean_rstd.numel() == x.size(0) * x.size(3) * 2, op, ": mean_rstd is [B][C][2]");
+  TORCH_CHECK(t == 4 && span_y >= 2 && span_y <= 3 && span_x >= 2 && span_x <= 3, op,
+              ": covers the DownSample operators only (4 taps, starts 2 or 3 apart)");
+  const int dt = dtype_code(x, op);
+  O2M_CALL(op, x, o2m_instnorm_act_resample2d(ptr(x), ptr<float>(mean_rstd), ptr(y), ptr<int32_t>(sy), ptr<float>(wy), ptr<int32_t>(sx),
+                                             ptr<float>(wx), i32(x.size(0), op), i32(x.size(1), op), i32(x.size(2), op),
+                                             i32(y.size(1), op), i32(y.size(2), op), i32(x.size(3), op), i32(t, op), i32(span_y, op),
+                                             i32(span_x, op), i32(act, op), dt, stream));
+}
+
+void instnorm_resample_bwd(const Tensor& g_coarse, const Tensor& x, const Tensor& mean_rstd, Tensor& partial, Tensor& gsums, Tensor& gx,
+                           const Tensor& sy, const Tensor& wy, const Tensor& sx, const Tensor& wx, int64_t t, int64_t act) {
+  const char* op = "o2m::instnorm_resample_bwd";
+  chk(g_coarse, op, "g_coarse"); chk(x, op, "x"); chk_f32(mean_rstd, op, "mean_rstd"); chk_f32(partial, op, "partial");
+  chk_f32(gsums, op, "gsums"); chk(gx, op, "gx"); chk(sy, op, "sy"); chk_f32(wy, op, "wy"); chk(sx, op, "sx"); chk_f32(wx, op, "wx");
+  TORCH_CHECK(x.dim() == 4 && g_coarse.dim() == 4 && gx.sizes() == x.sizes() && g_coarse.size(0) == x.size(0) &&
+                  g_coarse.size(3) == x.size(3), op, ": x, gx [B][H][W][C]; g_coarse [B][Hl][Wl][C]");
+  same_dtype(x, g_coarse, op, "x", "g_coarse"); same_dtype(x, gx, op, "x", "gx");
+  TORCH_CHECK(sy.scalar_type() == at::kInt && sx.scalar_type() == at::kInt, op, ": tap starts are int32");
+  TORCH_CHECK(sy.numel() == x.size(1) && sx.numel() == x.size(2) && wy.numel() == x.size(1) * t && wx.numel() == x.size(2) * t, op,
+              ": the TRANSPOSED operator's taps are [H] / [H][T] and [W] / [W][T]");
+  TORCH_CHECK(partial.numel() >= static_cast<int64_t>(o2m_instnorm_ws_floats(x.size(0), x.size(1) * x.size(2), x.size(3))) &&
+                  gsums.numel() == x.size(0) * x.size(3) * 2 && mean_rstd.numel() == gsums.numel(), op, ": workspace sizes");
+  const int dt = dtype_code(x, op);
+  O2M_CALL(op, x, o2m_instnorm_resample_bwd(ptr(g_coarse), ptr(x), ptr<float>(mean_rstd), ptr<float>(partial), ptr<float>(gsums), ptr(gx),
+                                           ptr<int32_t>(sy), ptr<float>(wy), ptr<int32_t>(sx), ptr<float>(wx), i32(x.size(0), op),
+                                           i32(x.size(1), op), i32(x.size(2), op), i32(g_coarse.size(1), op), i32(g_coarse.size(2), op),
+                                           i32(x.size(3), op), i32(t, op), i32(act, op), dt, stream));
+}
+
 int64_t chan_partials_floats(int64_t B, int64_t P, int64_t C, int64_t nv) {
   const char* op = "o2m::chan_partials_floats";
   return static_cast<int64_t>(o2m_chan_partials_floats(i32(B, op), i32(P, op), i32(C, op), i32(nv, op)));
@@ -582,6 +622,10 @@ TORCH_LIBRARY(o2m, m) {
   m.def("instnorm_stats(Tensor x, Tensor(a!) partial, Tensor(b!) mean_rstd, float eps) -> ()");
   m.def("instnorm_apply(Tensor x, Tensor mean_rstd, Tensor? residual, Tensor(a!) y, int act) -> ()");
   m.def("instnorm_bwd(Tensor g, Tensor x, Tensor mean_rstd, Tensor(a!) partial, Tensor(b!) gsums, Tensor(c!) gx, int act) -> ()");
+  m.def("instnorm_act_resample2d(Tensor x, Tensor mean_rstd, Tensor(a!) y, Tensor sy, Tensor wy, Tensor sx, Tensor wx, int t, int span_y, "
+        "int span_x, int act) -> ()");
+  m.def("instnorm_resample_bwd(Tensor g_coarse, Tensor x, Tensor mean_rstd, Tensor(a!) partial, Tensor(b!) gsums, Tensor(c!) gx, "
+        "Tensor sy, Tensor wy, Tensor sx, Tensor wx, int t, int act) -> ()");
   m.def("resample2d(Tensor x, Tensor(a!) y, Tensor sy, Tensor wy, Tensor sx, Tensor wx, int ty, int tx, int span_y, int span_x) -> ()");
   m.def("ada_grid_sample(Tensor x, Tensor theta, Tensor(a!) y) -> ()");
   m.def("ada_grid_sample_bwd(Tensor gy, Tensor theta, Tensor(a!) gx) -> ()");
@@ -618,6 +662,8 @@ TORCH_LIBRARY(o2m, m) {
   m.impl("conv2d_dots_finalize", &conv2d_dots_finalize); \
   m.impl("instnorm_apply", &instnorm_apply);      \
   m.impl("instnorm_bwd", &instnorm_bwd);          \
+  m.impl("instnorm_act_resample2d", &instnorm_act_resample2d); \
+  m.impl("instnorm_resample_bwd", &instnorm_resample_bwd); \
   m.impl("resample2d", &resample2d);              \
   m.impl("ada_grid_sample", &ada_grid_sample);    \
   m.impl("ada_grid_sample_bwd", &ada_grid_sample_bwd); \

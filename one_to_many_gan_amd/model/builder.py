@@ -107,11 +107,15 @@ class Generator(nn.Module):
     def _encode(self, t):
         mods = list(self.encoder)
         t = mods[1].run_norm_act(t, reflect=3, act=H.ACT_RELU)
-        for m in mods[4:]:
-            if isinstance(m, EqualisedConv2d):
-                t = m.run_norm_act(t, act=H.ACT_RELU)
-            elif isinstance(m, (DownSample, ResnetBlock)):
-                t = m.run(t)
+        k = 4
+        while k < len(mods):
+            m = mods[k]
+            if isinstance(m, EqualisedConv2d):  # conv, norm, relu, DownSample: slots k .. k + 3
+                t = m.run_norm_act_down(t, mods[k + 3], act=H.ACT_RELU)
+                k += 4
+            else:
+                t = m.run(t)  # ResnetBlock
+                k += 1
         return t
 
     def _decode(self, t, w, collect: bool, internal: bool = False):
@@ -184,8 +188,8 @@ def _patch_trunk(input_nc: int):
 
 def _run_trunk(mods, t):
     t = mods[2].run(mods[0].run(t, act=H.ACT_LRELU))
-    t = mods[6].run(mods[3].run_norm_act(t, act=H.ACT_LRELU))
-    t = mods[10].run(mods[7].run_norm_act(t, act=H.ACT_LRELU))
+    t = mods[3].run_norm_act_down(t, mods[6], act=H.ACT_LRELU)
+    t = mods[7].run_norm_act_down(t, mods[10], act=H.ACT_LRELU)
     return mods[11].run_norm_act(t, act=H.ACT_LRELU)
 
 

@@ -96,6 +96,14 @@ class EqualisedConv2d(nn.Module):
         y, stats = self.run(t, reflect=reflect, norm_eps=eps, link=head_link)
         return ops.instance_norm_act(y, act, residual=residual, eps=eps, stats=stats, link=tail_link)
 
+    def run_norm_act_down(self, t, down, *, act: int = H.ACT_NONE, eps: float = 1e-5):
+        """conv -> InstanceNorm2d -> activation -> DownSample ``down`` (builder.py:170-173,272-282) with the last
+        three as ONE pass over the conv output when the operator allows it."""
+        y, stats = self.run(t, norm_eps=eps)
+        if ops.norm_down_fusable(y, down.kind, stats):
+            return ops.instance_norm_act_down(y, act, down.kind, stats)
+        return down.run(ops.instance_norm_act(y, act, eps=eps, stats=stats))
+
     def forward(self, x: torch.Tensor):
         return ops.to_public(self.run(ops.to_internal(x)), self.out_features)
 

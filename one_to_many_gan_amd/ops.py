@@ -1054,6 +1054,52 @@ def split_batch(t, k):
     return _SplitBatchFn.apply(t, k)
 
 
+# O2M_FUSED_NORM_DOWN=0: InstanceNorm + activation and the DownSample behind it as two passes (round-2 form)
+_FUSED_NORM_DOWN = _os.environ.get("O2M_FUSED_NORM_DOWN", "1") == "1"
+
+
+class _InstNormDownFn(torch.autograd.Function):
+    """y = DownSample(act(InstanceNorm2d(x))) in one pass (builder.py:170-173,272-282); the normalised map is
+    neither stored nor needed: the backward gathers the fine gradient D^T g inside both InstanceNorm passes."""
+
+    @staticmethod
+    def forward(ctx, x, mr, act, kind):
+        B, Hh, Ww, Cn = x.shape
+        sy, wy, sx, wx, T, ho, wo = R.taps(kind, Hh, Ww, False, x.device)
+        y = torch.empty((B, ho, wo, Cn), dtype=x.dtype, device=x.device)
+        H.instnorm_act_resample2d(x, mr, y, sy, wy, sx, wx, int(T), T.span_y, T.span_x, act)
+        ctx.act, ctx.kind = act, kind
+        ctx.save_for_backward(x, mr)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, mr = ctx.saved_tensors
+        g = g.contiguous()
+        B, Hh, Ww, Cn = x.shape
+        sy, wy, sx, wx, T, _, _ = R.taps(ctx.kind, Hh, Ww, True, x.device)  # the transposed operator: fine <- coarse
+        ws = torch.empty(H.instnorm_ws_floats(B, Hh * Ww, Cn), dtype=torch.float32, device=x.device)
+        gs = torch.empty((B, Cn, 2), dtype=torch.float32, device=x.device)
+        gx = torch.empty_like(x)
+        H.instnorm_resample_bwd(g, x, mr, ws, gs, gx, sy, wy, sx, wx, int(T), ctx.act)
+        return gx, None, None, None
+
+
+def norm_down_fusable(x, kind, stats) -> bool:
+    """Whether instance_norm_act + resample(kind) can run as the fused pair: statistics in hand, a DownSample
+    operator the kernels cover (4 taps forward / 2 taps transposed), no activation tap being recorded."""
+    if not _FUSED_NORM_DOWN or stats is None or ACT_TAP is not None or kind not in ("down", "down_nosmooth"):
+        return False
+    Hh, Ww = x.shape[1], x.shape[2]
+    T = R.taps(kind, Hh, Ww, False, x.device)[4]
+    Tt = R.taps(kind, Hh, Ww, True, x.device)[4]
+    return int(T) == 4 and T.span_y in (2, 3) and T.span_x in (2, 3) and int(Tt) == 2
+
+
+def instance_norm_act_down(x, act, kind, stats):
+    return _InstNormDownFn.apply(x, stats, act, kind)
+
+
 # -------------------------------------------------------------------------------- resample
 
 

@@ -771,3 +771,36 @@ def test_batched_weight_preparation_equals_the_per_layer_launches():
                 if a is not None:
                     assert torch.equal(a, b)
     pk.set_precision("bf16")
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_fused_instance_norm_activation_downsample_matches_the_two_passes(dt):
+    """o2m_instnorm_act_resample2d / o2m_instnorm_resample_bwd (InstanceNorm + (Leaky)ReLU + DownSample as one pass,
+    and its backward gathering the fine gradient) against instance_norm_act followed by resample, forward and
+    input gradient, on even and odd map sizes (the encoder's and the discriminator's)."""
+    import one_to_many_gan_amd as pk
+    from one_to_many_gan_amd import _hip as H
+    from one_to_many_gan_amd import ops
+
+    pk.set_precision("fp32" if dt == torch.float32 else "bf16")
+    try:
+        torch.manual_seed(31)
+        for (B, Hh, Ww, C, act) in ((2, 64, 64, 32, H.ACT_RELU), (3, 126, 126, 16, H.ACT_LRELU), (2, 62, 30, 64, H.ACT_LRELU)):
+            x = (torch.randn(B, Hh, Ww, C, device="cuda") * 2 + 0.3).to(dt)
+            ws = torch.empty(H.instnorm_ws_floats(B, Hh * Ww, C), device="cuda")
+            mr = torch.empty(B, C, 2, device="cuda")
+            H.instnorm_stats(x, ws, mr, 1e-5)
+            assert ops.norm_down_fusable(x, "down", mr)
+            xa = x.clone().requires_grad_(True)
+            xb = x.clone().requires_grad_(True)
+            ya = ops.resample(ops.instance_norm_act(xa, act, eps=1e-5, stats=mr), "down")
+            yb = ops.instance_norm_act_down(xb, act, "down", mr)
+            g = torch.randn_like(ya)
+            ya.backward(g)
+            yb.backward(g)
+            torch.cuda.synchronize()
+            tol = 2e-6 if dt == torch.float32 else 1.5e-2  # (bf16: the two-pass form rounds the normalised map first)
+            assert float((ya.float() - yb.float()).norm() / ya.float().norm()) < tol
+            assert float((xa.grad.float() - xb.grad.float()).norm() / xa.grad.float().norm()) < (2e-5 if dt == torch.float32 else 3e-2)
+    finally:
+        pk.set_precision("bf16")
