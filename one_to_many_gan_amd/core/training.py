@@ -120,6 +120,9 @@ def discriminator_step(config, device, discriminator, generator, mapping_network
 
 
 _BATCH_DECODES = os.environ.get("O2M_BATCH_DECODES", "1") == "1"
+# O2M_SIDE_STYLE=0: both style-extractor passes of generator_step on the main stream (A/B of running them beside the
+# encoder / the discriminator on the second stream)
+_SIDE_STYLE = os.environ.get("O2M_SIDE_STYLE", "1") == "1"
 
 
 def _separate_decodes(config, device, generator, discriminator, mapping_network, style_extractor, ada, latents,
@@ -146,7 +149,7 @@ def _separate_decodes(config, device, generator, discriminator, mapping_network,
 
 
 def _batched_decodes(config, device, generator, discriminator, mapping_network, style_extractor, ada, t_lat,
-                     shoeprints, shoemarks):
+                     shoeprints, shoemarks, w_mark=None, mark_ready=None):
     """The same five decoder passes as TWO: the three decodes (training.py:171-199) as one 3B batch and the two
     feature extractions (training.py:226-231) as one 2B batch.  The decoder is per-sample throughout (style
     modulation / demodulation per sample, no normalisation), so every sample's result is that of its separate
@@ -156,7 +159,11 @@ def _batched_decodes(config, device, generator, discriminator, mapping_network, 
     # Every style vector first, in the reference's draw order (builder.py:115-128, training.py:214-223:
     # get_single_w(1) -> theta -> h -> get_two_w; get_single_w(0) and the style extractor draw nothing) ...
     w_zero = mapping_network.get_single_w(batch, blocks, device, 0)
-    w_mark = style_extractor(shoemarks)
+    if w_mark is None:
+        w_mark = style_extractor(shoemarks)
+    else:  # computed on the second stream beside the encoder (generator_step): order the main stream behind it
+        torch.cuda.current_stream(device).wait_event(mark_ready)
+        w_mark.record_stream(torch.cuda.current_stream(device))
     w_trans = mapping_network.get_single_w(batch, blocks, device, 1)
     theta = torch.rand(batch).to(device)
     lo, hi = lam["path_loss_jacobian_granularity"]
@@ -188,16 +195,28 @@ def _batched_decodes(config, device, generator, discriminator, mapping_network, 
     rec = ops.l1_sum(rec_t, ops.to_internal(shoeprints)) / n_img
     idt = ops.l1_sum(idt_t, ops.to_internal(shoemarks)) / n_img
     generated = ops.to_public(gen_t, shoeprints.shape[1])
+    style_of_generated = None
+    if side is not None and _SIDE_STYLE:
+        # the style extractor's pass over the generated images beside the discriminator's (independent networks,
+        # one input): on the second stream, behind the extraction group
+        made = torch.cuda.Event()
+        made.record(main)
+        side.wait_event(made)
+        gen_t.record_stream(side)
+        with torch.cuda.stream(side):
+            style_of_generated = style_extractor(generated)
     with _frozen(discriminator):
         gan = _mse_to(discriminator(ada(generated)), 1.0)
 
-    style = style_cycle_loss_func(w_trans[-1], style_extractor(generated))
-
+    if style_of_generated is None:
+        style_of_generated = style_extractor(generated)
     if side is None:
         path = extraction_group()
     else:
         main.wait_stream(side)
         path.record_stream(main)
+        style_of_generated.record_stream(main)
+    style = style_cycle_loss_func(w_trans[-1], style_of_generated)
     return rec, idt, gan, style, path
 
 
@@ -218,6 +237,17 @@ def generator_step(config, device, generator, discriminator, mapping_network, st
     shoeprints = next(shoeprint_iter).to(device)
     shoemarks = next(shoemark_iter).to(device)
 
+    # the style of the real shoemarks does not depend on the generator: its pass runs on the second stream beside
+    # the encoder (and its backward beside whatever the main stream does then)
+    w_mark = mark_ready = None
+    side = ops.group_stream(device) if (_BATCH_DECODES and _SIDE_STYLE) else None
+    if side is not None:
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            w_mark = style_extractor(shoemarks)
+            mark_ready = torch.cuda.Event()
+            mark_ready.record(side)
+
     # both domains through the encoder in one 2B pass; KL on the joint latent
     latents = generator.encode(torch.cat([shoeprints, shoemarks], dim=0))
     kl = kl_loss_func(latents, moment_hook=kl_moment_hook)
@@ -230,7 +260,7 @@ def generator_step(config, device, generator, discriminator, mapping_network, st
                                                        style_extractor, ada, latents, shoeprints, shoemarks)
     else:
         rec, idt, gan, style, path = _batched_decodes(config, device, generator, discriminator, mapping_network,
-                                                      style_extractor, ada, t_lat, shoeprints, shoemarks)
+                                                      style_extractor, ada, t_lat, shoeprints, shoemarks, w_mark, mark_ready)
 
     total = (gan + lam["identity_loss_lambda"] * idt + lam["reconstruction_loss_lambda"] * rec
              + lam["kl_loss_lambda"] * kl + lam["path_loss_lambda"] * path
