@@ -237,9 +237,19 @@ class PreparedWeight:
         segment's all-reduce under the rest of backward (dist.BucketReducer)."""
         self.bwd_uses += 1
         if self.bwd_uses == self.fwd_uses and _early_finalize():
+            if device.type != "cuda":  # (the gloo rehearsal of the reducer on CPU tensors)
+                _finalize_layer(self)
+                return
+            cur = torch.cuda.current_stream(device)
             wst = _wgrad_stream(device)
             if wst is not None:
-                torch.cuda.current_stream(device).wait_stream(wst)
+                cur.wait_stream(wst)
+            # the layer's other uses may have been reduced on the other compute stream (generator_step runs the
+            # decode group and the extraction group on two streams): their style-path accumulations must have
+            # landed before the accumulators are converted and handed to the all-reduce
+            for other in (torch.cuda.default_stream(device), _GSTREAM.get(device)):
+                if other is not None and other != cur:
+                    cur.wait_stream(other)
             _finalize_layer(self)
 
     def fp8_ok(self, data_grad: bool, rows: int) -> bool:
