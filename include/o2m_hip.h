@@ -224,11 +224,7 @@ typedef struct {
   const float* gy_scale; /* [B][Co] or NULL    */
   int32_t B, H, W, Ci, Co, KH, KW, pad, pad_mode, dtype;
   int32_t splits;        /* >=1: number of slices of the pixel reduction; 0 = auto */
-  int32_t nseg;          /* 0/1: only (x, gy).  2..8: the reduction also runs over the extra
-                            (x_seg[i], gy_seg[i]) pairs, i = 1..nseg-1, all of the same shape: the
-                            uses of ONE filter in a backward pass (a decoder filter is applied to
-                            5 batches per generator step) reduced by a single launch.  Requires
-                            Wo % 32 == 0 and no in_scale / gy_scale. */
+  int32_t reserved0;     /* (round 1-2: segment count of a multi-operand launch; removed with the batched decoder groups) */
   int32_t stride;        /* 0/1: unit stride; >1: gy is the output of a strided conv
                             (Ho = (H + 2 pad - KH) / stride + 1)                          */
   int32_t kernel_hint;   /* 0: the register-staged tiles.  O2M_WGRAD_HINT_P8 (1): the phase-pipelined 256 x 256
@@ -242,8 +238,6 @@ typedef struct {
                             there and a second kernel adds the slices to dw in slice order -- bitwise
                             reproducible (the reference's deterministic_cuda_kernels switch, train.py:41-45)
                             and faster: plain stores run at ~4-5x the chip-wide float-atomic rate. */
-  const void* x_seg[8];  /* [0] ignored (= x)  */
-  const void* gy_seg[8]; /* [0] ignored (= gy) */
 } o2m_wgrad_desc;
 #define O2M_WGRAD_HINT_P8 1
 int o2m_conv2d_wgrad(const o2m_wgrad_desc* d, void* stream);

@@ -59,8 +59,7 @@ class WgradDesc(C.Structure):
     _fields_ = [("x", _vp), ("gy", _vp), ("dw", _vp), ("in_scale", _vp), ("gy_scale", _vp),
                 ("B", _i32), ("H", _i32), ("W", _i32), ("Ci", _i32), ("Co", _i32), ("KH", _i32),
                 ("KW", _i32), ("pad", _i32), ("pad_mode", _i32), ("dtype", _i32), ("splits", _i32),
-                ("nseg", _i32), ("stride", _i32), ("kernel_hint", _i32), ("slabs", _vp), ("x_seg", _vp * 8),
-                ("gy_seg", _vp * 8)]
+                ("reserved0", _i32), ("stride", _i32), ("kernel_hint", _i32), ("slabs", _vp)]
 
 
 # name -> (restype, argtypes); mirrors include/o2m_hip.h one for one
@@ -259,22 +258,20 @@ _SLABS = _StreamScratch(16 << 20)  # (device, stream) -> fp32 workspace of the s
 WGRAD_ATOMICS = os.environ.get("O2M_WGRAD_ATOMICS", "0") == "1"  # A/B: float atomics instead of slab + reduce
 
 
-def _slab_workspace(x, gy, dw, pad, pad_mode, splits, n_more, stride, hint):
+def _slab_workspace(x, gy, dw, pad, pad_mode, splits, stride, hint):
     if WGRAD_ATOMICS and not DETERMINISTIC:
         return None
-    need = ops().conv2d_wgrad_slab_floats(x, gy, dw, pad, pad_mode, splits, n_more, stride, hint)
+    need = ops().conv2d_wgrad_slab_floats(x, gy, dw, pad, pad_mode, splits, stride, hint)
     return _SLABS.get(x.device, need)
 
 
-def conv2d_wgrad(x, gy, dw, *, in_scale=None, gy_scale=None, pad, pad_mode, splits=0, more=(), stride=1, p8=False):
-    """``more``: extra (x, gy) pairs of the same shape reduced by the same launch (<= 7).
-    The pixel slices go through a slab workspace + ordered second-stage sum (deterministic; see
+def conv2d_wgrad(x, gy, dw, *, in_scale=None, gy_scale=None, pad, pad_mode, splits=0, stride=1, p8=False):
+    """The pixel slices go through a slab workspace + ordered second-stage sum (deterministic; see
     o2m_wgrad_desc.slabs) unless O2M_WGRAD_ATOMICS=1.  ``p8``: prefer the phase-pipelined kernel where it applies
     (o2m_wgrad_desc.kernel_hint)."""
-    mx, mg = [p[0] for p in more], [p[1] for p in more]
     hint = 1 if p8 else 0
-    slabs = _slab_workspace(x, gy, dw, pad, pad_mode, splits, len(more), stride, hint)
-    return ops().conv2d_wgrad(x, gy, dw, in_scale, gy_scale, pad, pad_mode, splits, mx, mg, stride, slabs, hint)
+    slabs = _slab_workspace(x, gy, dw, pad, pad_mode, splits, stride, hint)
+    return ops().conv2d_wgrad(x, gy, dw, in_scale, gy_scale, pad, pad_mode, splits, stride, slabs, hint)
 
 
 DETERMINISTIC = False  # ops.set_deterministic(): ordered two-stage sums instead of fp32 atomics

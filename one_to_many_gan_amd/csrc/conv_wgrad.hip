@@ -32,17 +32,6 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
 }
 
-// Segment pointer by constant-index selects: a dynamic index into the by-value descriptor would
-// spill it to scratch and turn the buffer resource into a per-lane value (waterfall loops
-// around every buffer load).
-__device__ __forceinline__ const void* seg_ptr(const void* first, const void* const (&arr)[8], int seg) {
-  const void* p = first;
-#pragma unroll
-  for (int i = 1; i < 8; ++i)
-    if (seg == i) p = arr[i];
-  return p;
-}
-
 template <typename T> struct Stg;
 template <> struct Stg<unsigned short> { u32x4 v; };
 template <> struct Stg<float> { f32x4 a, b; };
@@ -129,9 +118,7 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const o2m_wgrad_desc 
   const int st = d.stride > 0 ? d.stride : 1;
   const int Ho = (H + 2 * pad - KH) / st + 1, Wo = (W + 2 * pad - KW) / st + 1;
   const int HoWo = Ho * Wo;
-  const int nseg = d.nseg > 1 ? d.nseg : 1;
-  const int Mseg = d.B * HoWo;  // rows of one (x, gy) segment
-  const int M = nseg * Mseg;
+  const int M = d.B * HoWo;
   const int K = KH * KW * Ci;
   const bool reflect = d.pad_mode == O2M_PAD_REFLECT;
   // ALIGNED (Wo % BMR == 0): a stage never leaves its image row (nor its segment).  A template
@@ -147,10 +134,8 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const o2m_wgrad_desc 
   const int m_end = min(M, m_begin + rows_per_split);
   if (m_begin >= m_end) return;  // uniform per block
 
-  // buffer descriptors of the segment the current stage reads (rebuilt when it changes)
-  int cur_seg = m_begin / Mseg;  // uniform
-  rsrc_t xr = make_rsrc(seg_ptr(d.x, d.x_seg, cur_seg), (unsigned)((size_t)d.B * H * W * Ci * ES));
-  rsrc_t gr = make_rsrc(seg_ptr(d.gy, d.gy_seg, cur_seg), (unsigned)((size_t)Mseg * Co * ES));
+  const rsrc_t xr = make_rsrc(d.x, (unsigned)((size_t)d.B * H * W * Ci * ES));
+  const rsrc_t gr = make_rsrc(d.gy, (unsigned)((size_t)M * Co * ES));
 
   const int tid = threadIdx.x;
   // ---- G (upstream gradient) loader: rows grow0 + GRS*j, 8 channels at co0 + gc*8 --------
@@ -169,15 +154,14 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const o2m_wgrad_desc 
   int pb[XLD], py[XLD], px[XLD];
 #pragma unroll
   for (int j = 0; j < XLD; ++j) {
-    const int m = (m_begin + xr0 + XRS * j) % Mseg;
+    const int m = m_begin + xr0 + XRS * j;
     pb[j] = m / HoWo;
     const int rem = m - pb[j] * HoWo;
     py[j] = rem / Wo;
     px[j] = rem - py[j] * Wo;
   }
   // aligned path: (sample, row) of the whole stage are scalar
-  const int mb_loc = m_begin % Mseg;
-  int sb = mb_loc / HoWo, sy = (mb_loc - sb * HoWo) / Wo, sx = mb_loc - sb * HoWo - sy * Wo;
+  int sb = m_begin / HoWo, sy = (m_begin - sb * HoWo) / Wo, sx = m_begin - sb * HoWo - sy * Wo;
 
   // two register sets: stage i+2 is in flight while stage i+1 waits to be written to LDS
   Stg<T> sg[2][GLD], sx_[2][XLD];
@@ -195,14 +179,7 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const o2m_wgrad_desc 
     xsc[slot][XS ? j : 0][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(scr, (int)off + 16, 0, 0));
   };
   auto load_stage = [&](const int slot, int ms) {
-    const int seg = min(ms / Mseg, nseg - 1);  // uniform; stages never straddle segments
-    if (seg != cur_seg) {
-      cur_seg = seg;
-      xr = make_rsrc(seg_ptr(d.x, d.x_seg, seg), (unsigned)((size_t)d.B * H * W * Ci * ES));
-      gr = make_rsrc(seg_ptr(d.gy, d.gy_seg, seg), (unsigned)((size_t)Mseg * Co * ES));
-      sb = 0; sy = 0; sx = 0;  // a new segment starts at its first pixel
-    }
-    const int mloc0 = ms - seg * Mseg;
+    const int mloc0 = ms;
 #pragma unroll
     for (int j = 0; j < GLD; ++j) {
       const int m = ms + grow0 + GRS * j;
@@ -599,7 +576,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_p8_kernel(const o2m_wgrad_d
 // the layers the phase-pipelined weight-gradient kernel takes; *splits / *rows: its slicing of the image rows
 inline bool wgrad_p8_ok(const o2m_wgrad_desc& d, long* splits, long* rows) {
   if (d.kernel_hint != O2M_WGRAD_HINT_P8 || d.dtype != O2M_BF16 || d.Co != 256 || d.Ci != 256 || d.KH != 3 || d.KW != 3 || d.pad != 1 || d.stride > 1 ||
-      d.W != 64 || d.in_scale || d.gy_scale || d.nseg > 1 || d.splits > 0)
+      d.W != 64 || d.in_scale || d.gy_scale || d.splits > 0)
     return false;
   const long r_total = (long)d.B * d.H;
   if (r_total < 28 * 8) return false;  // >= 8 K-tiles per slice
@@ -616,7 +593,7 @@ int launch_cfg(const o2m_wgrad_desc& d, hipStream_t s, size_t* slab_floats = nul
   constexpr int lds = 2 * (F32 ? 2 : 1) * BMR * ((BCO * 2 + 64) + (BKO * 2 + 64));
   const int st = d.stride > 0 ? d.stride : 1;
   const int Ho = (d.H + 2 * d.pad - d.KH) / st + 1, Wo = (d.W + 2 * d.pad - d.KW) / st + 1;
-  const long M = (long)(d.nseg > 1 ? d.nseg : 1) * d.B * Ho * Wo;
+  const long M = (long)d.B * Ho * Wo;
   const int K = d.KH * d.KW * d.Ci;
   const int tiles_co = (d.Co + BCO - 1) / BCO, tiles_k = (K + BKO - 1) / BKO;
   long splits = d.splits;
@@ -725,7 +702,7 @@ int launch_dtype_r2(const o2m_wgrad_desc& d, hipStream_t s, size_t* slab_floats)
     // 128x64 / 64x128 wave tiles (1.5x fewer LDS fragment bytes per MFMA) where they measured
     // faster (tools/sweep_wgrad.py): long reductions for wide layers, K a multiple of 256
     const int st = d.stride > 0 ? d.stride : 1;
-    const long M = (long)(d.nseg > 1 ? d.nseg : 1) * d.B * ((d.H + 2 * d.pad - d.KH) / st + 1) *
+    const long M = (long)d.B * ((d.H + 2 * d.pad - d.KH) / st + 1) *
                    ((d.W + 2 * d.pad - d.KW) / st + 1);
     if (d.Co > 256 || (d.Co > 128 && M >= 100000)) return launch_cfg<T, 256, 128, 2, 2>(d, s, slab_floats);
     if (d.Co > 64 && d.Co <= 128 && K % 256 == 0 && sizeof(T) == 2)  // fp32 split: would spill
@@ -763,7 +740,6 @@ static int wgrad_run(const o2m_wgrad_desc* d, void* stream, size_t* slab_floats)
   const long x_sample = (long)d->H * d->W * (long)d->Ci * esz, g_sample = howo * (long)d->Co * esz;
   if (x_sample > 0x7fffffffL || g_sample > 0x7fffffffL) return O2M_ERR_UNSUPPORTED;
   if ((long)d->B * x_sample > 0x7fffffffL || (long)d->B * g_sample > 0x7fffffffL) {
-    if (d->nseg > 1) return O2M_ERR_UNSUPPORTED;
     const long big = x_sample > g_sample ? x_sample : g_sample;
     const int per = (int)(0x7fffffffL / big);
     size_t most = 0;
@@ -781,14 +757,6 @@ static int wgrad_run(const o2m_wgrad_desc* d, void* stream, size_t* slab_floats)
     }
     if (slab_floats) *slab_floats = most;
     return 0;
-  }
-  if (d->nseg < 0 || d->nseg > 8) return O2M_ERR_BAD_ARG;
-  if (d->nseg > 1) {
-    const int wo = (d->W + 2 * d->pad - d->KW) / st + 1;
-    if (wo % 32 != 0 || d->in_scale || d->gy_scale) return O2M_ERR_BAD_ARG;
-    if ((long)d->nseg * d->B * howo > 0x7fffffffL) return O2M_ERR_UNSUPPORTED;
-    for (int i = 1; i < d->nseg; ++i)
-      if (!d->x_seg[i] || !d->gy_seg[i]) return O2M_ERR_BAD_ARG;
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (d->dtype == O2M_BF16) return launch_dtype<unsigned short>(*d, s, slab_floats);

@@ -173,46 +173,38 @@ int64_t conv2d_stats_rows(const Tensor& x, const Tensor& w, const Tensor& y, int
 }
 
 static void fill_wgrad_dims(o2m_wgrad_desc& d, const Tensor& x, const Tensor& dw, int64_t pad, int64_t pad_mode, int64_t splits,
-                            int64_t nseg, int64_t stride, const char* op, int64_t hint = 0) {
+                            int64_t stride, const char* op, int64_t hint = 0) {
   d.kernel_hint = i32(hint, op);
   d.B = i32(x.size(0), op); d.H = i32(x.size(1), op); d.W = i32(x.size(2), op); d.Ci = i32(x.size(3), op);
   d.Co = i32(dw.size(0), op); d.KH = i32(dw.size(1), op); d.KW = i32(dw.size(2), op);
   d.pad = i32(pad, op); d.pad_mode = i32(pad_mode, op); d.dtype = dtype_code(x, op); d.splits = i32(splits, op);
-  d.nseg = i32(nseg, op); d.stride = i32(stride, op);
+  d.stride = i32(stride, op);
 }
 
 int64_t conv2d_wgrad_slab_floats(const Tensor& x, const Tensor& gy, const Tensor& dw, int64_t pad, int64_t pad_mode, int64_t splits,
-                                 int64_t n_more, int64_t stride, int64_t hint) {
+                                 int64_t stride, int64_t hint) {
   const char* op = "o2m::conv2d_wgrad_slab_floats";
   TORCH_CHECK(x.dim() == 4 && gy.dim() == 4 && dw.dim() == 4, op, ": x, gy are NHWC; dw is [Co][KH][KW][Ci]");
   o2m_wgrad_desc d{};
-  fill_wgrad_dims(d, x, dw, pad, pad_mode, splits, 1 + n_more, stride, op, hint);
+  fill_wgrad_dims(d, x, dw, pad, pad_mode, splits, stride, op, hint);
   return static_cast<int64_t>(o2m_conv2d_wgrad_slab_floats(&d));
 }
 
 void conv2d_wgrad(const Tensor& x, const Tensor& gy, Tensor& dw, const OptT& in_scale, const OptT& gy_scale,
-                  int64_t pad, int64_t pad_mode, int64_t splits, at::TensorList more_x, at::TensorList more_gy,
-                  int64_t stride, const std::optional<Tensor>& slabs, int64_t hint) {
+                  int64_t pad, int64_t pad_mode, int64_t splits, int64_t stride, const std::optional<Tensor>& slabs,
+                  int64_t hint) {
   const char* op = "o2m::conv2d_wgrad";
   chk_f32(slabs, op, "slabs");
   chk(x, op, "x"); chk(gy, op, "gy"); chk_f32(dw, op, "dw"); chk_f32(in_scale, op, "in_scale"); chk_f32(gy_scale, op, "gy_scale");
   TORCH_CHECK(x.dim() == 4 && gy.dim() == 4 && dw.dim() == 4, op, ": x, gy are NHWC; dw is [Co][KH][KW][Ci]");
   same_dtype(x, gy, op, "x", "gy");
   TORCH_CHECK(dw.size(3) == x.size(3) && dw.size(0) == gy.size(3) && gy.size(0) == x.size(0), op, ": shapes of x / gy / dw disagree");
-  TORCH_CHECK(more_x.size() == more_gy.size() && more_x.size() <= 7, op, ": at most 7 extra (x, gy) segments");
   o2m_wgrad_desc d{};
   d.x = ptr(x); d.gy = ptr(gy); d.dw = ptr<float>(dw); d.in_scale = fptr(in_scale); d.gy_scale = fptr(gy_scale);
-  fill_wgrad_dims(d, x, dw, pad, pad_mode, splits, 1 + static_cast<int64_t>(more_x.size()), stride, op, hint);
+  fill_wgrad_dims(d, x, dw, pad, pad_mode, splits, stride, op, hint);
   if (slabs.has_value()) {
     TORCH_CHECK(static_cast<size_t>(slabs->numel()) >= o2m_conv2d_wgrad_slab_floats(&d), op, ": slab workspace too small");
     d.slabs = ptr<float>(slabs);
-  }
-  for (size_t i = 0; i < more_x.size(); ++i) {
-    chk(more_x[i], op, "more_x[i]"); chk(more_gy[i], op, "more_gy[i]");
-    TORCH_CHECK(more_x[i].sizes() == x.sizes() && more_gy[i].sizes() == gy.sizes() &&
-                    more_x[i].scalar_type() == x.scalar_type() && more_gy[i].scalar_type() == gy.scalar_type(),
-                op, ": wgrad segments must share one shape and dtype");
-    d.x_seg[i + 1] = ptr(more_x[i]); d.gy_seg[i + 1] = ptr(more_gy[i]);
   }
   O2M_CALL(op, x, o2m_conv2d_wgrad(&d, stream));
 }
@@ -605,8 +597,8 @@ TORCH_LIBRARY(o2m, m) {
   m.def("conv2d_stats_rows(Tensor x, Tensor w, Tensor y, int pad, int stride) -> int");
   m.def("instnorm_finalize(Tensor partial, Tensor(a!) mean_rstd, int P, int nchunks, float eps) -> ()");
   m.def("conv2d_wgrad(Tensor x, Tensor gy, Tensor(a!) dw, Tensor? in_scale, Tensor? gy_scale, int pad, int pad_mode, int splits, "
-        "Tensor[] more_x, Tensor[] more_gy, int stride, Tensor(b!)? slabs=None, int kernel_hint=0) -> ()");
-  m.def("conv2d_wgrad_slab_floats(Tensor x, Tensor gy, Tensor dw, int pad, int pad_mode, int splits, int n_more, int stride, "
+        "int stride, Tensor(b!)? slabs=None, int kernel_hint=0) -> ()");
+  m.def("conv2d_wgrad_slab_floats(Tensor x, Tensor gy, Tensor dw, int pad, int pad_mode, int splits, int stride, "
         "int kernel_hint=0) -> int");
   m.def("wgrad_finalize(Tensor(a!) acc, Tensor(b!)? gq, Tensor w32, Tensor(c!) grad, int co, int ci, float c) -> ()");
   m.def("prepare_weights(Tensor w, Tensor(a!) full, Tensor(b!) w_f, Tensor(c!) w_d, Tensor(d!)? q, Tensor(e!)? qt, float c) -> ()");

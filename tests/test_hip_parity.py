@@ -121,7 +121,7 @@ def test_fp8_mode_matches_oracle_and_fixture(name, golden_dir):
 
 
 SHARED_MASK_CASES = [n for n in OP_CASES if n.startswith(NET_CASES)]
-# Measured on MI355X (tools/parity_report.py --shared-masks, profiles/r02_shared_mask_parity.txt): with the
+# Measured on MI355X (tools/parity_report.py --shared-masks, profiles/r02_shared_masks_report.txt): with the
 # masks shared, the fp32-mode gradients sit this far from the fp64 oracle, per case (worst tensor).
 SHARED_MASK_TOL = 1e-3
 

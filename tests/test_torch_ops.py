@@ -42,9 +42,9 @@ def test_meta_kernels_check_shapes_and_cpu_is_rejected():
         ops.instnorm_apply(_meta(2, 8, 8, 16).permute(0, 2, 1, 3), _meta(2, 16, 2, dtype=torch.float32), None,
                            _meta(2, 8, 8, 16), 0)
     dw = _meta(32, 3, 3, 16, dtype=torch.float32)
-    ops.conv2d_wgrad(x, y, dw, None, None, 1, 0, 0, [], [], 1)
-    with pytest.raises(RuntimeError, match="one shape"):
-        ops.conv2d_wgrad(x, y, dw, None, None, 1, 0, 0, [_meta(2, 8, 8, 8)], [y], 1)
+    ops.conv2d_wgrad(x, y, dw, None, None, 1, 0, 0, 1)
+    with pytest.raises(RuntimeError, match="shapes of x / gy / dw disagree"):
+        ops.conv2d_wgrad(_meta(2, 8, 8, 8), y, dw, None, None, 1, 0, 0, 1)
     with pytest.raises(RuntimeError, match="workspace too small"):
         ops.instnorm_stats(x, _meta(1, dtype=torch.float32), _meta(2, 16, 2, dtype=torch.float32), 1e-5)
     with pytest.raises(RuntimeError, match="dtype must be bfloat16 or float32"):
