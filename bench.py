@@ -179,7 +179,7 @@ def kernel_profile(trainer, precision, steps=3):
     peak = MFMA_PEAK[precision] / 1e12
     # HBM/fabric bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE
     # with the gfx950 correction), committed under profiles/: PMC cannot be read from inside the run
-    traffic = None
+    traffic = traffic_of = None
     import glob
 
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_igemm*.json")), reverse=True):
@@ -187,6 +187,8 @@ def kernel_profile(trainer, precision, steps=3):
             rec = json.load(open(path))
             if rec.get("kernel") == name:
                 traffic = rec["fabric_bytes_per_launch"]
+                traffic_of = {"shape": rec.get("shape"), "algorithmic_bytes": rec.get("algorithmic_bytes_per_launch"),
+                              "file": os.path.basename(path)}
                 break
         except (OSError, ValueError, KeyError):
             pass
@@ -199,7 +201,7 @@ def kernel_profile(trainer, precision, steps=3):
     mfma_flops = sum(v[2] for v in agg.values())
     return {
         "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-        "frac": round(achieved / peak, 4), "traffic": traffic,
+        "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_measured_on": traffic_of,
         "kernel": name, "launches_per_step": round(n, 1), "avg_launch_us": round(secs / n * 1e6, 2),
         "measured": "single-stream steps (the kernel alone on the chip)",
         "in_timed_region": (None if not in_step or name not in in_step else {
