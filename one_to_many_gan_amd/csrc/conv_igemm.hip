@@ -684,6 +684,10 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
   constexpr int BM = 256, BN = 256, NT = 512;
   constexpr int OPB = 32768;   // one operand of one K-tile: 256 rows x 128 B
   constexpr int BUFB = 65536;  // A + B
+#ifndef O2M_P8_DIRECT_EPI
+#define O2M_P8_DIRECT_EPI 1  // (0: the LDS-staged epilogue of rounds 1-3, for A/B builds, tools/build_variant.sh)
+#endif
+  constexpr bool DIRECT = O2M_P8_DIRECT_EPI;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int H = d.H, W = d.W, Ci = d.Ci, Co = d.Co, KH = d.KH, KW = d.KW, pad = d.pad;
@@ -717,40 +721,50 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
   auto slot_row = [&](int q) { const int pr = 4 * q + (lane >> 4); return 2 * pr + (((lane & 15) ^ (pr & 15)) >> 3); };
   auto slot_chk = [&](int q) { const int pr = 4 * q + (lane >> 4); return ((lane & 15) ^ (pr & 15)) & 7; };
 
+  // Per fill (8 pixels; this lane's pixel = its slot row): cbase = byte offset of the pixel's own (centre) element +
+  // this lane's 16-B chunk, msk = which taps stay inside the image: bit ky (rows), bit 8 + kx (columns), bit 16 = the
+  // output row exists.  A tap's address is then  cbase + ty + tx  with ty = +-(ky - pad) W Ci, tx = +-(kx - pad) Ci
+  // bytes: a cleared bit means zero fill (ZERO padding: out-of-range offset) or the mirrored element (REFLECT, pad 1:
+  // the sign of that component flips) -- a handful of VALU per border fill and K-tile instead of the full gather.
   const RowDiv by_howo(HoWo, M), by_wo(Wo, M);
-  int pix[4], ryx[4];
+  unsigned cbase[4], msk[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int m = m0 + slot_row(a_group(j));
+    cbase[j] = 0;
+    msk[j] = 0;
     if (m < M) {
       const int b = by_howo.div(m), rem = m - b * HoWo;
       const int oy = by_wo.div(rem), ox = rem - oy * Wo;
-      pix[j] = (b * H + oy) * W + ox;
-      ryx[j] = (oy << 16) | ox;
-    } else {
-      pix[j] = -1;
-      ryx[j] = 0;
+      cbase[j] = (unsigned)(((b * H + oy) * W + ox) * Ci * ES + slot_chk(a_group(j)) * 16);
+      unsigned mk = 1u << 16;
+      for (int ky = 0; ky < KH; ++ky) mk |= (unsigned)((unsigned)(oy + ky - pad) < (unsigned)H) << ky;
+      for (int kx = 0; kx < KW; ++kx) mk |= (unsigned)((unsigned)(ox + kx - pad) < (unsigned)W) << (8 + kx);
+      msk[j] = mk;
     }
   }
   unsigned dwoff[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int q = b_group(j);
-    const int n = n0 + slot_row(q);
+    // DIRECT: LDS filter row rho = 64 wcol + 16 j + i holds output channel 64 wcol + 32 (j >> 1) + 8 (i >> 2) +
+    // 4 (j & 1) + (i & 3), so that the accumulators of one lane are 8 CONSECUTIVE channels (see the epilogue)
+    const int rho = slot_row(q);
+    const int n = n0 + (DIRECT ? (rho & ~63) + 32 * ((rho >> 5) & 1) + 8 * ((rho >> 2) & 3) + 4 * ((rho >> 4) & 1) + (rho & 3)
+                               : rho);
     dwoff[j] = n < Co ? (unsigned)(n * K * ES + slot_chk(q) * 16) : OOB_OFF;
   }
   unsigned aoff[4];
   // Interior fills: all 8 pixels of the fill have their whole KH x KW window inside the image.  Their lane
   // offset points at the window's first tap once and for all; the tap only moves the fill's SGPR offset,
-  // so walking the taps costs such a fill no vector instructions.  Border fills keep the per-tap offsets.
+  // so walking the taps costs such a fill no vector instructions.  Border fills combine cbase / msk per tap.
   unsigned inner = 0;  // bit j (wave-uniform)
+  const unsigned full = (1u << 16) | (((1u << KW) - 1) << 8) | ((1u << KH) - 1);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int oy = ryx[j] >> 16, ox = ryx[j] & 0xffff;
-    const bool in = pix[j] >= 0 && oy >= pad && oy - pad + KH <= H && ox >= pad && ox - pad + KW <= W;
-    if (__all(in)) {
+    if (__all(msk[j] == full)) {
       inner |= 1u << j;
-      aoff[j] = (unsigned)((pix[j] - pad * W - pad) * Ci * ES + slot_chk(a_group(j)) * 16);
+      aoff[j] = cbase[j] - (unsigned)((pad * W + pad) * Ci * ES);
     }
   }
   inner = __builtin_amdgcn_readfirstlane(inner);
@@ -759,26 +773,39 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
   unsigned a_tap[2] = {0, 0};  // byte offset of the tap inside the window (interior fills)
   int b_kt[2] = {0, 0};
 
+#ifndef O2M_P8_CHUNK_OUTER
+#define O2M_P8_CHUNK_OUTER 0  // (1: A/B builds, tools/build_variant.sh)
+#endif
+  // Walk of the reduction: CHANNEL CHUNK outer, the KH x KW taps inner.  The nine taps of one 64-channel chunk re-read
+  // the same 128-B slice of every pixel row, so an XCD's 32 resident tiles work on 32 x (256 + halo) x 128 B = 1.2 MB
+  // at a time and the taps after the first hit its 4 MB L2; with the taps outer every tap walked the whole 512-B rows
+  // (4 MB per XCD, plus filters and the output stream: nothing stayed; FETCH_SIZE 193 MB -> 63 MB per B = 48 launch,
+  // profiles/r03_z_pmc_igemm_p8.json vs r03_y_pmc_igemm_p8.json).
+  // Filters are [tap][co][ci]: K-tile (tap, chunk) sits at reduction offset tap * Ci + chunk in either walk.
+  // Every tile starts at its own chunk (tile index mod the chunk count, then cyclically): neighbouring tiles of an XCD
+  // would otherwise all sit on the SAME 128-B column of the 512-B pixel rows for nine K-tiles, i.e. on a quarter of
+  // the L2 channels.
+  constexpr bool CHUNK_OUTER = O2M_P8_CHUNK_OUTER;
+#ifndef O2M_P8_CHUNK_ROTATE
+#define O2M_P8_CHUNK_ROTATE 1
+#endif
+  const int cb0 = (CHUNK_OUTER && O2M_P8_CHUNK_ROTATE) ? ((tile / tiles_n) % (Ci / KT)) * KT : 0;
+  int b_tap[2] = {0, 0}, b_cb[2] = {cb0, cb0}, a_n[2] = {0, 0};
+  if constexpr (CHUNK_OUTER) a_cb[0] = a_cb[1] = cb0;
   auto issue_a = [&](int r) {
-    if (a_cb[r] == 0) {  // first K-tile of a tap: gather offsets of this region's two fills
-      const int dy = a_ky[r] - pad, dx = a_kx[r] - pad;
-      const bool live = a_ky[r] < KH;  // past the reduction: zero fills, no traffic
+    const bool live = CHUNK_OUTER ? a_n[r] < nk : a_ky[r] < KH;  // past the reduction: zero fills, no traffic
+    if (CHUNK_OUTER || a_cb[r] == 0) {  // a new tap: offsets of this region's border fills
       if (!live) inner &= ~(3u << (2 * r));
       a_tap[r] = (unsigned)((a_ky[r] * W + a_kx[r]) * Ci * ES);
+      const unsigned sdy = (unsigned)((a_ky[r] - pad) * W * Ci * ES), sdx = (unsigned)((a_kx[r] - pad) * Ci * ES);
+      const unsigned need = live ? (1u << 16) | (reflect ? 0u : (1u << a_ky[r]) | (1u << (8 + a_kx[r]))) : ~0u;
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
         const int j = 2 * r + jj;
         if (inner >> j & 1) continue;
-        const int oy = ryx[j] >> 16, ox = ryx[j] & 0xffff;
-        int iy = oy + dy, ix = ox + dx;
-        bool ok = live && pix[j] >= 0;
-        if (reflect) {
-          iy = iy < 0 ? -iy : (iy >= H ? 2 * H - 2 - iy : iy);
-          ix = ix < 0 ? -ix : (ix >= W ? 2 * W - 2 - ix : ix);
-        } else {
-          ok = ok && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-        }
-        aoff[j] = ok ? (unsigned)((pix[j] + (iy - oy) * W + (ix - ox)) * Ci * ES + slot_chk(a_group(j)) * 16) : OOB_OFF;
+        const unsigned ty = (msk[j] >> a_ky[r] & 1) ? sdy : 0u - sdy;  // (only REFLECT gets here with a cleared bit)
+        const unsigned tx = (msk[j] >> (8 + a_kx[r]) & 1) ? sdx : 0u - sdx;
+        aoff[j] = (msk[j] & need) == need ? cbase[j] + ty + tx : OOB_OFF;
       }
     }
     char* dst = smem + a_buf[r] * BUFB;
@@ -790,22 +817,40 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
           __builtin_amdgcn_readfirstlane(a_cb[r] * ES + ((inner >> j & 1) ? a_tap[r] : 0u)), 0, 0);
     }
     a_buf[r] ^= 1;
-    a_cb[r] += KT;
-    if (a_cb[r] == Ci) {
-      a_cb[r] = 0;
-      if (++a_kx[r] == KW) { a_kx[r] = 0; ++a_ky[r]; }
+    if constexpr (CHUNK_OUTER) {
+      ++a_n[r];
+      if (++a_kx[r] == KW) {
+        a_kx[r] = 0;
+        if (++a_ky[r] == KH) {
+          a_ky[r] = 0;
+          a_cb[r] += KT;
+          if (a_cb[r] == Ci) a_cb[r] = 0;
+        }
+      }
+    } else {
+      a_cb[r] += KT;
+      if (a_cb[r] == Ci) {
+        a_cb[r] = 0;
+        if (++a_kx[r] == KW) { a_kx[r] = 0; ++a_ky[r]; }
+      }
     }
   };
   auto issue_b = [&](int r) {
     const bool live = b_kt[r] < nk;
     char* dst = smem + (b_kt[r] & 1) * BUFB + OPB;
+    const int koff = CHUNK_OUTER ? (b_tap[r] * Ci + b_cb[r]) * ES : b_kt[r] * 128;
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
       const int j = 2 * r + jj;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void*)(dst + b_group(j) * 1024), 16,
-                                               (int)(live ? dwoff[j] : OOB_OFF), b_kt[r] * 128, 0, 0);
+                                               (int)(live ? dwoff[j] : OOB_OFF), koff, 0, 0);
     }
     ++b_kt[r];
+    if (++b_tap[r] == KH * KW) {
+      b_tap[r] = 0;
+      b_cb[r] += KT;
+      if (b_cb[r] == Ci) b_cb[r] = 0;
+    }
   };
 
   // ---- fragments ------------------------------------------------------------------------------------
@@ -852,9 +897,15 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           f32x4_t& c = acc[mh * 4 + i][nh * 2 + j];
-          if constexpr (FMT == 0) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][ks], bf[j][ks], c, 0, 0, 0);
-          else if constexpr (FMT == 1) c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(af[i][ks], bf[j][ks], c, 0, 0, 0);
-          else c = __builtin_amdgcn_mfma_f32_16x16x32_bf8_fp8(af[i][ks], bf[j][ks], c, 0, 0, 0);
+          if constexpr (DIRECT) {  // filter rows as the A operand: a lane's 4 result registers are 4 CHANNELS of one pixel
+            if constexpr (FMT == 0) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][ks], af[i][ks], c, 0, 0, 0);
+            else if constexpr (FMT == 1) c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(bf[j][ks], af[i][ks], c, 0, 0, 0);
+            else c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(bf[j][ks], af[i][ks], c, 0, 0, 0);
+          } else {
+            if constexpr (FMT == 0) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][ks], bf[j][ks], c, 0, 0, 0);
+            else if constexpr (FMT == 1) c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(af[i][ks], bf[j][ks], c, 0, 0, 0);
+            else c = __builtin_amdgcn_mfma_f32_16x16x32_bf8_fp8(af[i][ks], bf[j][ks], c, 0, 0, 0);
+          }
         }
     __builtin_amdgcn_s_setprio(0);
   };
@@ -907,15 +958,13 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
 #undef P8_WAIT_AND_SYNC
 #undef P8_CLOSE
   if (wrow == 0) __builtin_amdgcn_s_barrier();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the zero fills issued past the end of the reduction
-  __syncthreads();
+  if constexpr (!DIRECT) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the zero fills issued past the end of the reduction
+    __syncthreads();
+  }
 
-  // ---- epilogue: fp32 tile through LDS, whole channel vectors out (as in conv_igemm_kernel) -------------
-  constexpr int CSTR = BN + 4;
-  float* csm = reinterpret_cast<float*>(smem);
   T* __restrict__ Y = static_cast<T*>(d.y);
   const T* __restrict__ R = static_cast<const T*>(d.residual);
-  constexpr int VPR = BN / 8;
   const int act = d.act;
   const float deq = (FMT != 0 && d.deq_scale) ? d.deq_scale[0] * d.deq_scale[2] : 1.f;  // {1/scale, amax} of x, of w
   // outputs of >= 64 MiB leave through non-temporal stores, as in conv_igemm_kernel (no cache level holds them for
@@ -927,6 +976,132 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
   const bool dot_mode = d.stats && d.stats_mode == O2M_STATS_DOT;
   const T* __restrict__ AUX = static_cast<const T*>(d.aux);
   T* __restrict__ AUXS = static_cast<T*>(d.aux_scaled);
+
+  if constexpr (DIRECT) {
+    // ---- epilogue straight from the accumulators -------------------------------------------------------
+    // The filter rows were the A operand and sit permuted in LDS (dwoff above), so lane l of acc[i][2h], acc[i][2h+1]
+    // holds, for pixel 16 i + (l & 15) of the wave's 128, the EIGHT consecutive channels 32 h + 8 (l >> 4) .. + 7 of
+    // the wave's 64: one 16-B vector of the output row, 64 B per pixel per store instruction.  No LDS staging, no
+    // barrier: a wave leaves as soon as its own 16 vectors per lane are out (the staged form cost two passes of
+    // 128 ds_write_b32 per lane + 4 barriers: profiles/r02, 11 of the 71 us of a tile).
+    const int g = lane >> 4, pl = lane & 15;
+    const int mwave = m0 + 128 * wrow;
+    float esc[2][8], ebias[2][8];
+    int en[2];
+    bool col_ok[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      en[h] = n0 + 64 * wcol + 32 * h + 8 * g;
+      col_ok[h] = en[h] < Co;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { esc[h][q] = deq; ebias[h][q] = 0.f; }
+      if (col_ok[h]) {
+        if (d.out_scale && b_uniform) {
+          const float* sp = d.out_scale + (size_t)b_first * Co + en[h];
+          const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 4);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { esc[h][q] *= s0[q]; esc[h][4 + q] *= s1[q]; }
+        }
+        if (d.bias) {
+          const f32x4 b0 = *reinterpret_cast<const f32x4*>(d.bias + en[h]);
+          const f32x4 b1 = *reinterpret_cast<const f32x4*>(d.bias + en[h] + 4);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { ebias[h][q] = b0[q]; ebias[h][4 + q] = b1[q]; }
+        }
+      }
+    }
+    float st[2][16];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) st[h][q] = 0.f;
+    const float rdeq = 1.f / deq;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int m = mwave + 16 * i + pl;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (m >= M || !col_ok[h]) continue;
+        float o[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { o[r] = acc[i][2 * h][r]; o[4 + r] = acc[i][2 * h + 1][r]; }
+        const size_t off = (size_t)m * Co + en[h];
+        float xv[8];
+        if (dot_mode) {  // style dot of the data gradient: sum over pixels of (unscaled result) * aux
+          load8x(AUX + off, xv, stream_out);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) st[h][q] += o[q] * deq * xv[q];
+        }
+        if (d.out_scale && !b_uniform) {
+          const float* sp = d.out_scale + (size_t)(m / HoWo) * Co + en[h];
+          const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 4);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { o[q] *= s0[q] * deq; o[4 + q] *= s1[q] * deq; }
+          if (dot_mode && AUXS) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { xv[q] *= s0[q]; xv[4 + q] *= s1[q]; }
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) o[q] *= esc[h][q];
+          if (dot_mode && AUXS && d.out_scale) {  // (a one-sample tile: esc = dequantisation x out_scale)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) xv[q] *= esc[h][q] * rdeq;
+          }
+        }
+        if (dot_mode && AUXS) store8x(AUXS + off, xv, stream_out);  // aux * out_scale: the modulated input x * s
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] += ebias[h][q];
+        if (d.stats && !dot_mode) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) { st[h][q] += o[q]; st[h][8 + q] += o[q] * o[q]; }
+        }
+        act_fwd8(o, act);
+        if (R) {
+          float rv[8];
+          load8(R + off, rv);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) o[q] += rv[q];
+        }
+#ifdef O2M_P8_NOSTORE  // (timing experiment only: how much of a tile is the output burst)
+        if (o[0] == 12345.678f)
+#endif
+        store8x(Y + off, o, stream_out);
+      }
+    }
+    if (d.stats && mwave < M) {
+      // the wave's 128 pixels x 64 channels ARE one row of the partial table: sum over the 16 lanes that share a
+      // channel vector (quad swaps, then rotations inside the row of 16), fixed order, no LDS, no atomics
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          float v = st[h][q];
+          v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+          v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+          v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x124, 0xf, 0xf, true));  // row_ror:4
+          v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x128, 0xf, 0xf, true));  // row_ror:8
+          st[h][q] = v;
+        }
+      if (pl == 0) {
+        const size_t part = (size_t)(mwave / 128);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          if (!col_ok[h]) continue;
+          float* sp = d.stats + (part * Co + en[h]) * 2;  // [part][channel][sum | sum of squares]
+#pragma unroll
+          for (int q = 0; q < 8; q += 2)
+            *reinterpret_cast<f32x4*>(sp + 2 * q) = f32x4{st[h][q], st[h][8 + q], st[h][q + 1], st[h][8 + q + 1]};
+        }
+      }
+    }
+    return;
+  }
+
+  // ---- epilogue: fp32 tile through LDS, whole channel vectors out (as in conv_igemm_kernel) -------------
+  constexpr int CSTR = BN + 4;
+  float* csm = reinterpret_cast<float*>(smem);
+  constexpr int VPR = BN / 8;
   static_assert(NT % VPR == 0, "one channel vector per thread");
   const int ec8 = tid % VPR, erow = tid / VPR, en = n0 + ec8 * 8;
   const bool ecol_ok = en < Co;
@@ -1019,6 +1194,13 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
     if (d.stats && mbase < M) stats_block_reduce<NT, VPR>(st, csm, d.stats, (long)(mbase / 128), n0, Co, tid);
     if (pass == 0) lds_barrier();
   }
+}
+
+// what conv_igemm_p8_kernel's fills assume (beyond the dtype and the tile count, which the callers check)
+// what conv_igemm_p8_kernel's fills assume (beyond the dtype and the tile count, which the callers check)
+inline bool p8_geometry_ok(const o2m_conv_desc& d) {
+  return !d.in_scale && d.stride <= 1 && d.Ci % BK == 0 && d.KH <= 8 && d.KW <= 8 &&
+         (d.pad_mode != O2M_PAD_REFLECT || d.pad <= 1);  // mirrored taps as a sign flip: pad 1 only
 }
 
 int launch_p8(const o2m_conv_desc& d, hipStream_t s, long m_begin, long m_end) {
@@ -1318,7 +1500,7 @@ int launch_dtype(const o2m_conv_desc& d, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {
       // O2M_IGEMM_P8=0: the symmetric two-stage kernel instead of the phase-pipelined one (A/B runs)
       static const int p8 = [] { const char* e = getenv("O2M_IGEMM_P8"); return e ? atoi(e) : 1; }();
-      if (p8 && !d.in_scale && d.stride <= 1 && d.Ci % BK == 0 && tiles_for<256, 256>(d) >= kFillBlocks) {
+      if (p8 && p8_geometry_ok(d) && tiles_for<256, 256>(d) >= kFillBlocks) {
         // One block per CU and round: a few tiles past a whole number of rounds would cost a whole
         // extra round (the data gradient of the reflect-padded 64x64 layers is 273 tiles = 2 rounds for
         // 1.07 rounds of work).  Such a tail (<= 1/4 round) runs as a second launch of 128x128 tiles
@@ -1458,7 +1640,7 @@ extern "C" int o2m_conv2d_fwd(const o2m_conv_desc* d, void* stream) {
   if (f8) {
     // fp8 operands run on the phase-pipelined kernel only: a K-tile is 128 elements of one filter tap
     if (d->in_scale || d->stride > 1 || !d->deq_scale) return O2M_ERR_BAD_ARG;
-    if (d->Ci % 128 != 0) return O2M_ERR_UNSUPPORTED;
+    if (d->Ci % 128 != 0 || !p8_geometry_ok(*d)) return O2M_ERR_UNSUPPORTED;
     return launch_p8(*d, s, 0, out_rows(*d));
   }
   if (d->dtype == O2M_BF16) return launch_dtype<unsigned short>(*d, s);

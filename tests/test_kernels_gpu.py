@@ -175,6 +175,9 @@ FULL_SIZE_CONVS = [
     (16, 256, 256, 64, 128, 3, 1, False, "plain"),       # Co = 128, one 64-channel chunk
     (4, 256, 256, 128, 64, 3, 1, False, "modulated"),    # Co = 64, two chunks, per-sample filters + demodulation
     (2, 256, 256, 64, 64, 3, 1, False, "epilogue"),      # the minimum grid (512 tiles), bias + act + residual
+    # the p8 kernel's per-fill tap masks (border fills: zero fill or mirrored element per tap from a bit mask)
+    (20, 63, 63, 128, 256, 4, 1, False, "epilogue"),     # 4 x 4 taps, odd map (discriminator trunk), p8 + 128x128 tail
+    (16, 64, 64, 256, 256, 5, 2, True, "plain"),         # reflect pad 2: NOT the p8 kernel's geometry -> symmetric kernel
 ]
 
 
