@@ -113,6 +113,7 @@ def product_namespace(precision, ada_p=0.0):
     from one_to_many_gan_amd.model import loss as pl
 
     pk.set_precision(precision)
+    pt.set_async_scalars(True)  # as train.py runs the loop: the logged scalars are read at the log interval, not per step
     return SimpleNamespace(Discriminator=pb.Discriminator, Generator=pb.Generator,
                            MappingNetwork=pb.MappingNetwork, StyleExtractor=pb.StyleExtractor,
                            make_adam=pk.make_adam, ImageBuffer=pt.ImageBuffer, ADAp=pl.ADAp,
@@ -419,7 +420,7 @@ def main():
         "config": {"workload": f"{args.size}x{args.size}x{args.channels} D+G step (discriminator_step + "
                                f"generator_step), batch {args.batch}/GPU, stock config.toml hyper-parameters, "
                                f"ADA at p={args.ada_p:g}", "global_batch": args.batch * world,
-                   "parallelism": f"dp{world}", "last_losses": {"d": last[0][0], "g": last[1][0]}},
+                   "parallelism": f"dp{world}", "last_losses": {"d": float(last[0][0]), "g": float(last[1][0])}},
     }
     if flop:
         out["step_mfma_frac"] = round(images_per_sec * flop / (world * MFMA_PEAK[args.precision]), 4)

@@ -45,7 +45,7 @@ class Logger:
     def print(self, step: int) -> str:
         parts = [f"Step: {step}/{self.training_steps}"]
         for attr, label in _LINE:
-            mean = f"{np.mean(getattr(self, attr)):.6g}"
+            mean = f"{np.mean([float(v) for v in getattr(self, attr)]):.6g}"  # (float(): LoggedScalar entries)
             if label is None:  # second half of "real/fake"
                 parts[-1] += "/" + mean
             else:

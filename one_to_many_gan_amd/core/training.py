@@ -54,9 +54,89 @@ class ImageBuffer:
         return torch.cat(picked, 0)
 
 
+class _PendingScalars:
+    """The packed scalars of one step function on their way to the host: a non-blocking copy into pinned memory and
+    an event behind it.  The first read waits for that event only."""
+
+    __slots__ = ("host", "event", "values")
+
+    def __init__(self, packed: torch.Tensor):
+        self.host = torch.empty(packed.shape, dtype=torch.float32, pin_memory=True)
+        self.host.copy_(packed, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record(torch.cuda.current_stream(packed.device))
+        self.values = None
+
+    def get(self, i: int) -> float:
+        if self.values is None:
+            self.event.synchronize()
+            self.values = self.host.tolist()
+            self.host = None
+        return self.values[i]
+
+
+class LoggedScalar:
+    """A logged loss / confidence whose device->host copy may still be in flight.  ``float(x)`` (and every arithmetic
+    or comparison operator, ``format`` and ``math.*`` through it) waits for the copy on first use.  The reference reads
+    ten scalars per step with blocking ``.item()`` calls (training.py:13,125-128,250-257) and appends them to the
+    logger's lists; read this way the lists hold the same numbers at print time and the host is never made to wait
+    for the step it has just queued (``set_async_scalars``)."""
+
+    __slots__ = ("_pending", "_index")
+
+    def __init__(self, pending: _PendingScalars, index: int):
+        self._pending, self._index = pending, index
+
+    def __float__(self):
+        return self._pending.get(self._index)
+
+    def __repr__(self):
+        return repr(float(self))
+
+    def __format__(self, spec):
+        return format(float(self), spec)
+
+    def __bool__(self):
+        return bool(float(self))
+
+    def __hash__(self):
+        return hash(float(self))
+
+    def __neg__(self):
+        return -float(self)
+
+    def __abs__(self):
+        return abs(float(self))
+
+
+def _scalar_op(name):
+    def op(self, other):
+        return getattr(float, name)(float(self), float(other))
+
+    return op
+
+
+for _n in ("add", "radd", "sub", "rsub", "mul", "rmul", "truediv", "rtruediv", "pow", "rpow", "lt", "le", "gt", "ge",
+           "eq", "ne"):
+    setattr(LoggedScalar, f"__{_n}__", _scalar_op(f"__{_n}__"))
+
+_ASYNC_SCALARS = False
+
+
+def set_async_scalars(flag: bool) -> None:
+    """On: the step functions return ``LoggedScalar`` objects instead of floats (train.py and bench.py switch it on;
+    off by default so that a caller written against the reference gets plain floats)."""
+    global _ASYNC_SCALARS
+    _ASYNC_SCALARS = bool(flag) and os.environ.get("O2M_ASYNC_SCALARS", "1") != "0"  # (=0: A/B runs)
+
+
 def _floats(*scalars):
     """One device->host transfer for all logged scalars of a step."""
-    return torch.stack([s.detach().float().reshape(()) for s in scalars]).tolist()
+    packed = torch.stack([s.detach().float().reshape(()) for s in scalars])
+    if _ASYNC_SCALARS and packed.device.type == "cuda":
+        pending = _PendingScalars(packed)
+        return [LoggedScalar(pending, i) for i in range(len(scalars))]
+    return packed.tolist()
 
 
 def _l1(a, b):

@@ -361,8 +361,8 @@ def case_steps(ns, device, *, tag, nc, size, batch, n_steps=2, seed=1234, min_la
                                                  prints, marks, buf, ada, ada_p)
             gl, parts = ns.generator_step(cfg, device, nets["G"], nets["D"], nets["M"], nets["S"],
                                           opts["G"], opts["M"], opts["S"], prints, marks, ada)
-            out[f"step{s}/d"] = torch.tensor([dl, ra, fa])
-            out[f"step{s}/g"] = torch.tensor([gl, *parts])
+            out[f"step{s}/d"] = torch.tensor([float(v) for v in (dl, ra, fa)])  # (float(): LoggedScalar when async)
+            out[f"step{s}/g"] = torch.tensor([float(v) for v in (gl, *parts)])
     # post-step probes: network outputs on a fixed input are a smooth function of the
     # updated parameters (raw parameter checksums are dominated by sign(g) of tiny grads)
     with torch.no_grad():

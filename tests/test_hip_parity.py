@@ -230,3 +230,36 @@ def test_config4_step_at_full_size_is_finite_and_reproducible():
     assert float(a["step0/g"][0]) > 0 and float(a["step0/d"][0]) > 0
     diff = [k for k in a if not torch.equal(a[k], b[k])]
     assert not diff, diff
+
+
+@pytest.mark.gpu
+def test_async_logged_scalars_equal_the_blocking_read():
+    """core.training.set_async_scalars(True) (train.py, bench.py): the ten logged scalars of a D+G step come back as
+    LoggedScalar objects whose device->host copy is read on first use.  Deterministic mode, same seeds: their values
+    are bit for bit those of the blocking read, and the Logger line built from them is the same line."""
+    import one_to_many_gan_amd as pk
+    from one_to_many_gan_amd.core import training as pt
+    from one_to_many_gan_amd.core.evaluation import Logger
+
+    pk.set_deterministic(True)
+    try:
+        sync = run_case("steps64", product_ns("bf16"), "cuda")
+        pt.set_async_scalars(True)
+        lazy = run_case("steps64", product_ns("bf16"), "cuda")
+    finally:
+        pt.set_async_scalars(False)
+        pk.set_deterministic(False)
+    diff = [k for k in sync if not torch.equal(sync[k], lazy[k])]
+    assert not diff, diff
+
+    pending = pt._PendingScalars(torch.tensor([1.5, -2.0, 0.25], device="cuda"))
+    a, b, c = (pt.LoggedScalar(pending, i) for i in range(3))
+    assert pending.values is None  # nothing read yet
+    assert float(a) == 1.5 and a + 1 == 2.5 and 1 + a == 2.5 and a * b == -3.0 and abs(b) == 2.0 and -c == -0.25
+    assert f"{c:.3f}" == "0.250" and b < a and sum([a, b, c]) == -0.25 and np.isfinite(float(c))
+    lg_lazy, lg_plain = Logger(4), Logger(4)
+    for lg, vals in ((lg_lazy, (a, b, c)), (lg_plain, (1.5, -2.0, 0.25))):
+        for attr in vars(lg):
+            if attr.startswith("log_"):
+                getattr(lg, attr).extend(vals)
+    assert lg_lazy.print(4) == lg_plain.print(4)

@@ -28,7 +28,7 @@ import torch
 
 import one_to_many_gan_amd as o2m
 from one_to_many_gan_amd.core.evaluation import Logger, image_checkpoint, load_checkpoint, model_checkpoint
-from one_to_many_gan_amd.core.training import ImageBuffer, discriminator_step, generator_step
+from one_to_many_gan_amd.core.training import ImageBuffer, discriminator_step, generator_step, set_async_scalars
 from one_to_many_gan_amd.data.config import load_config
 from one_to_many_gan_amd.model.builder import Discriminator, Generator, MappingNetwork, StyleExtractor
 from one_to_many_gan_amd.model.loss import ADAp
@@ -101,6 +101,9 @@ def run(config, device, steps, shoeprint_iter, shoemark_iter, resume=None, log=p
                                 opts["M"], opts["S"], ada_p, image_buffer)
         log(f"resumed from {resume} at step {first}")
     logger = Logger(steps)
+    # the ten logged scalars of a step reach the logger's lists as LoggedScalar objects and are read when a line is
+    # printed: no blocking read per step (the reference's .item() calls, training.py:125-128,250-257)
+    set_async_scalars(device.type == "cuda")
     ev = config["evaluation"]
     t0 = time.perf_counter()
     for step in range(first, steps):
