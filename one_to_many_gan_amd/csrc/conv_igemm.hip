@@ -683,7 +683,6 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
   constexpr int KS = FMT ? 4 : 2;         // MFMA k-steps (32 elements each) per K-tile
   constexpr int BM = 256, BN = 256, NT = 512;
   constexpr int OPB = 32768;   // one operand of one K-tile: 256 rows x 128 B
-  constexpr int BUFB = 65536;  // A + B
 #ifndef O2M_P8_DIRECT_EPI
 #define O2M_P8_DIRECT_EPI 1  // (0: the LDS-staged epilogue of rounds 1-3, for A/B builds, tools/build_variant.sh)
 #endif
@@ -755,102 +754,77 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
     dwoff[j] = n < Co ? (unsigned)(n * K * ES + slot_chk(q) * 16) : OOB_OFF;
   }
   unsigned aoff[4];
-  // Interior fills: all 8 pixels of the fill have their whole KH x KW window inside the image.  Their lane
-  // offset points at the window's first tap once and for all; the tap only moves the fill's SGPR offset,
-  // so walking the taps costs such a fill no vector instructions.  Border fills combine cbase / msk per tap.
+  // Interior fills: all 8 pixels of the fill have their whole KH x KW window inside the image: their tap address is
+  // cbase + one wave-uniform byte offset (one v_add per tap).  Border fills combine cbase / msk per tap.
   unsigned inner = 0;  // bit j (wave-uniform)
   const unsigned full = (1u << 16) | (((1u << KW) - 1) << 8) | ((1u << KH) - 1);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    if (__all(msk[j] == full)) {
-      inner |= 1u << j;
-      aoff[j] = cbase[j] - (unsigned)((pad * W + pad) * Ci * ES);
-    }
-  }
+  for (int j = 0; j < 4; ++j)
+    if (__all(msk[j] == full)) inner |= 1u << j;
   inner = __builtin_amdgcn_readfirstlane(inner);
-  // per-region stream state (wave-uniform): next K-tile's tap (ky, kx), channel base, LDS buffer
-  int a_ky[2] = {0, 0}, a_kx[2] = {0, 0}, a_cb[2] = {0, 0}, a_buf[2] = {0, 0};
-  unsigned a_tap[2] = {0, 0};  // byte offset of the tap inside the window (interior fills)
-  int b_kt[2] = {0, 0};
 
-#ifndef O2M_P8_CHUNK_OUTER
-#define O2M_P8_CHUNK_OUTER 0  // (1: A/B builds, tools/build_variant.sh)
-#endif
-  // Walk of the reduction: CHANNEL CHUNK outer, the KH x KW taps inner.  The nine taps of one 64-channel chunk re-read
-  // the same 128-B slice of every pixel row, so an XCD's 32 resident tiles work on 32 x (256 + halo) x 128 B = 1.2 MB
-  // at a time and the taps after the first hit its 4 MB L2; with the taps outer every tap walked the whole 512-B rows
-  // (4 MB per XCD, plus filters and the output stream: nothing stayed; FETCH_SIZE 193 MB -> 63 MB per B = 48 launch,
-  // profiles/r03_z_pmc_igemm_p8.json vs r03_y_pmc_igemm_p8.json).
-  // Filters are [tap][co][ci]: K-tile (tap, chunk) sits at reduction offset tap * Ci + chunk in either walk.
-  // Every tile starts at its own chunk (tile index mod the chunk count, then cyclically): neighbouring tiles of an XCD
-  // would otherwise all sit on the SAME 128-B column of the 512-B pixel rows for nine K-tiles, i.e. on a quarter of
-  // the L2 channels.
-  constexpr bool CHUNK_OUTER = O2M_P8_CHUNK_OUTER;
-#ifndef O2M_P8_CHUNK_ROTATE
-#define O2M_P8_CHUNK_ROTATE 1
-#endif
-  const int cb0 = (CHUNK_OUTER && O2M_P8_CHUNK_ROTATE) ? ((tile / tiles_n) % (Ci / KT)) * KT : 0;
-  int b_tap[2] = {0, 0}, b_cb[2] = {cb0, cb0}, a_n[2] = {0, 0};
-  if constexpr (CHUNK_OUTER) a_cb[0] = a_cb[1] = cb0;
-  auto issue_a = [&](int r) {
-    const bool live = CHUNK_OUTER ? a_n[r] < nk : a_ky[r] < KH;  // past the reduction: zero fills, no traffic
-    if (CHUNK_OUTER || a_cb[r] == 0) {  // a new tap: offsets of this region's border fills
-      if (!live) inner &= ~(3u << (2 * r));
-      a_tap[r] = (unsigned)((a_ky[r] * W + a_kx[r]) * Ci * ES);
-      const unsigned sdy = (unsigned)((a_ky[r] - pad) * W * Ci * ES), sdx = (unsigned)((a_kx[r] - pad) * Ci * ES);
-      const unsigned need = live ? (1u << 16) | (reflect ? 0u : (1u << a_ky[r]) | (1u << (8 + a_kx[r]))) : ~0u;
+  // The loader half of a phase runs beside the partner wave's 16 MFMAs, which hold the issue priority: every VALU
+  // and every branch here is paid several times over (MI355X guide, "Two waves per SIMD"; the round-3 loop spent
+  // ~35 SALU + 6 VALU + 2 taken branches per phase on buffer parities, tap state and dead-fill selects and its
+  // loader half, not the MFMA half, set the phase length).  So:
+  //  * the K loop is unrolled by two and the LDS image is [A(0) | A(1) | B(0) | B(1)] (K-tile parity): every fragment
+  //    read and every fill destination is a compile-time offset from one base register (ds_read offset:imm, m0 = imm);
+  //  * a region's stream state is two scalars (channel-chunk byte offset, remaining advances) plus the tap; the
+  //    per-lane tap offsets are recomputed only when the chunk wraps (every Ci / 64 K-tiles);
+  //  * past the end of the reduction a region simply re-fetches its LAST K-tile into the buffer nobody reads any
+  //    more (2-3 extra L2 hits per tile) instead of selecting out-of-range offsets per fill.
+  const int CiB = Ci * ES;  // bytes of one pixel's channels = distance between taps kx, kx + 1
+  int a_ky[2] = {0, 0}, a_kx[2] = {0, 0}, a_cbB[2] = {0, 0}, a_left[2] = {nk - 1, nk - 1};
+  int b_koff[2] = {0, 0};
+  const int b_klast = (nk - 1) * 128;
+  int a_dst[4], b_dst[4];  // LDS byte offset of fill j inside its operand tile (wave-uniform)
 #pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
-        const int j = 2 * r + jj;
-        if (inner >> j & 1) continue;
+  for (int j = 0; j < 4; ++j) {
+    a_dst[j] = __builtin_amdgcn_readfirstlane(a_group(j) * 1024);
+    b_dst[j] = __builtin_amdgcn_readfirstlane(b_group(j) * 1024 + 2 * OPB);
+  }
+  auto new_tap = [&](int r) {  // lane offsets of region r's two fills for the tap (a_ky[r], a_kx[r])
+    const unsigned sdy = (unsigned)((a_ky[r] - pad) * W * CiB), sdx = (unsigned)((a_kx[r] - pad) * CiB);
+    const unsigned need = (1u << 16) | (reflect ? 0u : (1u << a_ky[r]) | (1u << (8 + a_kx[r])));
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int j = 2 * r + jj;
+      if (inner >> j & 1) {
+        aoff[j] = cbase[j] + (sdy + sdx);
+      } else {
         const unsigned ty = (msk[j] >> a_ky[r] & 1) ? sdy : 0u - sdy;  // (only REFLECT gets here with a cleared bit)
         const unsigned tx = (msk[j] >> (8 + a_kx[r]) & 1) ? sdx : 0u - sdx;
         aoff[j] = (msk[j] & need) == need ? cbase[j] + ty + tx : OOB_OFF;
       }
     }
-    char* dst = smem + a_buf[r] * BUFB;
+  };
+  new_tap(0);
+  new_tap(1);
+  auto issue_a = [&](int r, int buf) {  // (r, buf: literals at every call site)
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
       const int j = 2 * r + jj;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(
-          xr, (lds_void*)(dst + a_group(j) * 1024), 16, (int)aoff[j],
-          __builtin_amdgcn_readfirstlane(a_cb[r] * ES + ((inner >> j & 1) ? a_tap[r] : 0u)), 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void*)(smem + buf * OPB + a_dst[j]), 16, (int)aoff[j],
+                                               __builtin_amdgcn_readfirstlane(a_cbB[r]), 0, 0);
     }
-    a_buf[r] ^= 1;
-    if constexpr (CHUNK_OUTER) {
-      ++a_n[r];
-      if (++a_kx[r] == KW) {
-        a_kx[r] = 0;
-        if (++a_ky[r] == KH) {
-          a_ky[r] = 0;
-          a_cb[r] += KT;
-          if (a_cb[r] == Ci) a_cb[r] = 0;
-        }
-      }
-    } else {
-      a_cb[r] += KT;
-      if (a_cb[r] == Ci) {
-        a_cb[r] = 0;
+    if (a_left[r] > 0) {
+      --a_left[r];
+      a_cbB[r] += 128;
+      if (a_cbB[r] == CiB) {
+        a_cbB[r] = 0;
         if (++a_kx[r] == KW) { a_kx[r] = 0; ++a_ky[r]; }
+        new_tap(r);
       }
     }
   };
-  auto issue_b = [&](int r) {
-    const bool live = b_kt[r] < nk;
-    char* dst = smem + (b_kt[r] & 1) * BUFB + OPB;
-    const int koff = CHUNK_OUTER ? (b_tap[r] * Ci + b_cb[r]) * ES : b_kt[r] * 128;
+  auto issue_b = [&](int r, int buf) {
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
       const int j = 2 * r + jj;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void*)(dst + b_group(j) * 1024), 16,
-                                               (int)(live ? dwoff[j] : OOB_OFF), koff, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void*)(smem + buf * OPB + b_dst[j]), 16, (int)dwoff[j],
+                                               __builtin_amdgcn_readfirstlane(b_koff[r]), 0, 0);
     }
-    ++b_kt[r];
-    if (++b_tap[r] == KH * KW) {
-      b_tap[r] = 0;
-      b_cb[r] += KT;
-      if (b_cb[r] == Ci) b_cb[r] = 0;
-    }
+    b_koff[r] = min(b_koff[r] + 128, b_klast);
   };
 
   // ---- fragments ------------------------------------------------------------------------------------
@@ -863,10 +837,10 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
   constexpr int KSH = FMT ? 5 : 6;  // k-step -> byte XOR: 2 chunks (fp8) or 4 chunks (bf16)
   const int c0 = FMT ? (lane >> 5) : (lane >> 4), h0 = FMT ? ((lane >> 4) & 1) * 8 : 0;
   const int fa0 = tile_off(128 * wrow + (lane & 15), c0) + h0;
-  const int fb0 = tile_off(64 * wcol + (lane & 15), c0) + h0 + OPB;
+  const int fb0 = tile_off(64 * wcol + (lane & 15), c0) + h0 + 2 * OPB;
   frag_t af[4][KS], b0f[2][KS], b1f[2][KS];
   auto read_a = [&](int buf, int mh) {
-    const char* base = smem + buf * BUFB + mh * (64 * 128);
+    const char* base = smem + buf * OPB + mh * (64 * 128);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -874,7 +848,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
         af[i][ks] = *reinterpret_cast<const frag_t*>(base + ((fa0 ^ (((i & 1) << 7) | (ks << KSH))) + i * 2048));
   };
   auto read_b = [&](frag_t (&bf)[2][KS], int buf, int nh) {
-    const char* base = smem + buf * BUFB + nh * (32 * 128);
+    const char* base = smem + buf * OPB + nh * (32 * 128);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -917,43 +891,47 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
 #define P8_CLOSE() __builtin_amdgcn_s_barrier()
 
   // ---- prologue: regions needed by phases -1 .. 4 -------------------------------------------------------
-  issue_b(0);  // B0(0)
-  issue_a(0);  // A0(0)
-  issue_b(1);  // B1(0)
-  issue_a(1);  // A1(0)
-  issue_b(0);  // B0(1)
-  issue_a(0);  // A0(1)
+  issue_b(0, 0);  // B0(0)
+  issue_a(0, 0);  // A0(0)
+  issue_b(1, 0);  // B1(0)
+  issue_a(1, 0);  // A1(0)
+  issue_b(0, 1);  // B0(1)
+  issue_a(0, 1);  // A0(1)
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // B0(0), A0(0) have landed for every wave
   __builtin_amdgcn_s_barrier();
   if (wrow == 1) __builtin_amdgcn_s_barrier();  // this wave row runs one barrier behind the other
   read_b(b0f, 0, 0);
 
-  for (int t = 0; t < nk; ++t) {
-    const int cur = t & 1;
+  auto ktile = [&](int cur) {  // one K-tile out of buffer `cur` (a literal at both call sites)
     // p1: A0 x B0
     read_a(cur, 0);
-    issue_b(1);  // B1(t+1)
+    issue_b(1, cur ^ 1);  // B1(t+1)
     P8_WAIT_AND_SYNC();
     multiply(b0f, 0, 0);
     P8_CLOSE();
     // p2: A0 x B1
     read_b(b1f, cur, 1);
-    issue_a(1);  // A1(t+1)
+    issue_a(1, cur ^ 1);  // A1(t+1)
     P8_WAIT_AND_SYNC();
     multiply(b1f, 0, 1);
     P8_CLOSE();
     // p3: A1 x B1
     read_a(cur, 1);
-    issue_b(0);  // B0(t+2)
+    issue_b(0, cur);  // B0(t+2)
     P8_WAIT_AND_SYNC();
     multiply(b1f, 1, 1);
     P8_CLOSE();
     // p4: A1 x B0, then the next K-tile's B0 fragments (landed: waited for at the end of p3)
-    issue_a(0);  // A0(t+2)
+    issue_a(0, cur);  // A0(t+2)
     P8_WAIT_AND_SYNC();
     multiply(b0f, 1, 0);
     read_b(b0f, cur ^ 1, 0);
     P8_CLOSE();
+  };
+#pragma unroll 1
+  for (int t = 0; t < nk; t += 2) {
+    ktile(0);
+    if (t + 1 < nk) ktile(1);
   }
 #undef P8_WAIT_AND_SYNC
 #undef P8_CLOSE
