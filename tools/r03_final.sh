@@ -1,8 +1,10 @@
 #!/bin/bash
 # round-3 measurement set: default bench (JSON line), rocprof kernel tables of the default command and of the
 # single-stream run, PMC passes of the dominant kernel and the two new MFMA kernels
-out=$GRAFT_REPO_ROOT/gpurun_out/r03z; mkdir -p $out
+out=$GRAFT_REPO_ROOT/gpurun_out/r03zz; mkdir -p $out
 cd $GRAFT_REPO_ROOT
+timeout -k 10 1000 python -m pytest tests -m gpu -x -q > $out/gputest.log 2>&1 || { tail -60 $out/gputest.log; exit 1; }
+tail -2 $out/gputest.log
 python bench.py > $out/bench_default.json 2> $out/bench_default.err || { tail -20 $out/bench_default.err; exit 1; }
 echo "default bench done"; python -c "import json; d=json.load(open('$out/bench_default.json')); print(d['ms_per_step'], d['value'])"
 cd /tmp && export TMPDIR=/tmp
