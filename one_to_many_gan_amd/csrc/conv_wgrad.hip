@@ -376,7 +376,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(float* __restrict__ d
 // =============================================================================================
 __global__ __launch_bounds__(512, 2) void conv_wgrad_p8_kernel(const o2m_wgrad_desc d, const int rows_per_split) {
   constexpr int REG = 16384;   // one region image: 64 pixel rows x 256 B
-  constexpr int BUFB = 65536;  // A0 | A1 | B0 | B1 of one K-tile
+  // LDS image: region rho = 2 * operand + half (A0, A1, B0, B1), K-tile parity p: byte (2 rho + p) * REG -- every
+  // fragment read and fill destination is then a compile-time offset from one base register once the K loop is
+  // unrolled by two (as in conv_igemm_p8_kernel: no VALU and no parity arithmetic in the loader half of a phase)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __attribute__((address_space(3))) void lds_void;
 
@@ -418,37 +420,45 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_p8_kernel(const o2m_wgrad_d
       xoff[hf][jj] = ok ? (unsigned)(ix * Ci + kc0 + 32 * hf) * 2u : OOB_OFF;
     }
   }
-  // per-region stream state (wave-uniform): next K-tile
+  // per-region stream state (wave-uniform): the next K-tile's image row, clamped to the slice's last one -- past the end
+  // of the reduction a region re-fetches its last K-tile into the buffer nobody reads any more
+  const unsigned g_row = (unsigned)(W * Co * 2), x_row = (unsigned)(W * Ci * 2);
   int a_kt[2] = {0, 0}, b_kt[2] = {0, 0};
   int b_b[2], b_oy[2];  // sample / image row of the B regions' next K-tile
   b_b[0] = b_b[1] = r_begin / H;
   b_oy[0] = b_oy[1] = r_begin - b_b[0] * H;
+  const int fill0 = __builtin_amdgcn_readfirstlane(2 * wave * 1024);
 
-  auto issue_a = [&](int r) {
-    const int kt = a_kt[r];
-    const bool live = kt < nk;
-    char* dst = smem + (kt & 1) * BUFB + r * REG;
-    const unsigned soff = live ? (unsigned)(r_begin + kt) * (unsigned)(W * Co * 2) : 0u;
+  auto issue_a = [&](int r, int buf) {  // (r, buf: literals at every call site)
+    const unsigned soff = (unsigned)(r_begin + a_kt[r]) * g_row;
+    char* dst = smem + (2 * r + buf) * REG + fill0;
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(gr, (lds_void*)(dst + (2 * wave + jj) * 1024), 16,
-                                               (int)(live ? goff[r][jj] : OOB_OFF), (int)soff, 0, 0);
-    a_kt[r] = kt + 1;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(gr, (lds_void*)(dst + jj * 1024), 16, (int)goff[r][jj],
+                                               (int)__builtin_amdgcn_readfirstlane(soff), 0, 0);
+    a_kt[r] = min(a_kt[r] + 1, nk - 1);
   };
-  auto issue_b = [&](int r) {
-    const int kt = b_kt[r];
+  auto issue_b = [&](int r, int buf) {
     int iy = b_oy[r] + dy;
-    bool live = kt < nk;
+    bool row_ok = true;  // (wave-uniform)
     if (reflect) iy = iy < 0 ? -iy : (iy >= H ? 2 * H - 2 - iy : iy);
-    else live = live && (unsigned)iy < (unsigned)H;
-    char* dst = smem + (kt & 1) * BUFB + (2 + r) * REG;
-    const unsigned soff = live ? (unsigned)((b_b[r] * H + iy) * W) * (unsigned)(Ci * 2) : 0u;
+    else row_ok = (unsigned)iy < (unsigned)H;
+    char* dst = smem + 4 * REG + (2 * r + buf) * REG + fill0;
+    const unsigned soff = row_ok ? (unsigned)((b_b[r] * H + iy) * W) * (unsigned)(Ci * 2) : 0u;
+    if (row_ok) {
 #pragma unroll
-    for (int jj = 0; jj < 2; ++jj)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void*)(dst + (2 * wave + jj) * 1024), 16,
-                                               (int)(live ? xoff[r][jj] : OOB_OFF), (int)soff, 0, 0);
-    b_kt[r] = kt + 1;
-    if (++b_oy[r] == H) { b_oy[r] = 0; ++b_b[r]; }
+      for (int jj = 0; jj < 2; ++jj)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void*)(dst + jj * 1024), 16, (int)xoff[r][jj],
+                                                 (int)__builtin_amdgcn_readfirstlane(soff), 0, 0);
+    } else {  // a row of the zero padding: hardware zero fill
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void*)(dst + jj * 1024), 16, (int)OOB_OFF, 0, 0, 0);
+    }
+    if (b_kt[r] < nk - 1) {
+      ++b_kt[r];
+      if (++b_oy[r] == H) { b_oy[r] = 0; ++b_b[r]; }
+    }
   };
 
   // ---- fragments (transposing reads) --------------------------------------------------------------------
@@ -456,7 +466,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_p8_kernel(const o2m_wgrad_d
   const int g = lane >> 4, q = (lane >> 2) & 3, pq = lane & 3;
   const int fsw = (q << 1) | ((g & 1) << 3);
   const int fa0 = (8 * g + q) * 256 + (((8 * wrow + (pq >> 1)) ^ fsw) << 4) + 8 * (pq & 1);
-  const int fb0 = (8 * g + q) * 256 + (((4 * wcol + (pq >> 1)) ^ fsw) << 4) + 8 * (pq & 1) + 2 * REG;
+  const int fb0 = (8 * g + q) * 256 + (((4 * wcol + (pq >> 1)) ^ fsw) << 4) + 8 * (pq & 1) + 4 * REG;
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
   auto tr8 = [&](const char* a) {  // 8 consecutive pixel rows of this lane's column: two transposing reads
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a));
@@ -466,14 +476,14 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_p8_kernel(const o2m_wgrad_d
   };
   bf16x8 af[4][2], b0f[2][2], b1f[2][2];
   auto read_a = [&](int buf, int mh) {
-    const char* base = smem + buf * BUFB + mh * REG;
+    const char* base = smem + (2 * mh + buf) * REG;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) af[i][ks] = tr8(base + ((fa0 ^ (i << 5)) + ks * 8192));
   };
   auto read_b = [&](bf16x8 (&bf)[2][2], int buf, int nh) {
-    const char* base = smem + buf * BUFB + nh * REG;
+    const char* base = smem + (2 * nh + buf) * REG;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -503,38 +513,42 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_p8_kernel(const o2m_wgrad_d
   } while (0)
 
   // ---- prologue / main loop: the schedule of conv_igemm_p8_kernel, region for region ----------------------
-  issue_b(0);  // B0(0)
-  issue_a(0);  // A0(0)
-  issue_b(1);  // B1(0)
-  issue_a(1);  // A1(0)
-  issue_b(0);  // B0(1)
-  issue_a(0);  // A0(1)
+  issue_b(0, 0);  // B0(0)
+  issue_a(0, 0);  // A0(0)
+  issue_b(1, 0);  // B1(0)
+  issue_a(1, 0);  // A1(0)
+  issue_b(0, 1);  // B0(1)
+  issue_a(0, 1);  // A0(1)
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // B0(0), A0(0) have landed for every wave
   __builtin_amdgcn_s_barrier();
   if (wrow == 1) __builtin_amdgcn_s_barrier();  // this wave row runs one barrier behind the other
   read_b(b0f, 0, 0);
-  for (int t = 0; t < nk; ++t) {
-    const int cur = t & 1;
-    read_a(cur, 0);  // p1: A0 x B0
-    issue_b(1);      // B1(t+1)
+  auto ktile = [&](int cur) {  // one K-tile out of buffer `cur` (a literal at both call sites)
+    read_a(cur, 0);        // p1: A0 x B0
+    issue_b(1, cur ^ 1);   // B1(t+1)
     WP8_WAIT_AND_SYNC();
     multiply(b0f, 0, 0);
     __builtin_amdgcn_s_barrier();
-    read_b(b1f, cur, 1);  // p2: A0 x B1
-    issue_a(1);           // A1(t+1)
+    read_b(b1f, cur, 1);   // p2: A0 x B1
+    issue_a(1, cur ^ 1);   // A1(t+1)
     WP8_WAIT_AND_SYNC();
     multiply(b1f, 0, 1);
     __builtin_amdgcn_s_barrier();
-    read_a(cur, 1);  // p3: A1 x B1
-    issue_b(0);      // B0(t+2)
+    read_a(cur, 1);        // p3: A1 x B1
+    issue_b(0, cur);       // B0(t+2)
     WP8_WAIT_AND_SYNC();
     multiply(b1f, 1, 1);
     __builtin_amdgcn_s_barrier();
-    issue_a(0);  // p4: A1 x B0, then the next K-tile's B0 fragments (landed: waited for at the end of p3)
+    issue_a(0, cur);       // p4: A1 x B0, then the next K-tile's B0 fragments (landed: waited for at the end of p3)
     WP8_WAIT_AND_SYNC();
     multiply(b0f, 1, 0);
     read_b(b0f, cur ^ 1, 0);
     __builtin_amdgcn_s_barrier();
+  };
+#pragma unroll 1
+  for (int t = 0; t < nk; t += 2) {
+    ktile(0);
+    if (t + 1 < nk) ktile(1);
   }
 #undef WP8_WAIT_AND_SYNC
   if (wrow == 0) __builtin_amdgcn_s_barrier();

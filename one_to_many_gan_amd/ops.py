@@ -414,18 +414,16 @@ _WSTREAM: dict = {}
 
 
 # The phase-pipelined weight-gradient kernel (o2m_wgrad_desc.kernel_hint) holds a whole CU per block: alone on the
-# chip it is 1.1-1.3x faster than the register-staged tiles (B = 16 / 32 / 48: 767 / 877 / 915 vs 580 / 700 / 826
-# TFLOP/s on the 256 -> 256 layers), but on the weight-gradient stream BESIDE the main stream it keeps the HBM-bound
-# kernels of the following layers off the CUs for its whole run, and the step loses 0.3-0.4 ms (four same-box A/B
-# runs, profiles/README.md).  Default: used exactly when the weight gradient runs in-line on the main stream
-# (O2M_WGRAD_STREAM=0); O2M_WGRAD_P8=1 / 0 forces it.
-_WGRAD_P8 = _os.environ.get("O2M_WGRAD_P8")
+# chip it is 1.15-1.35x faster than the register-staged tiles (B = 16 / 32 / 48: 800 / 882 / 966 vs 580 / 700 / 826
+# TFLOP/s on the 256 -> 256 layers).  Mid-round-3 it lost 0.3-0.4 ms per step on the weight-gradient stream BESIDE the
+# main stream and was used only in-line; with its loader halves slimmed (conv_wgrad.hip) it gains 0.3 ms there too (four
+# same-box pairs, gpurun_out/r03v/ab.log) and is the default wherever its geometry applies.  O2M_WGRAD_P8=0 switches
+# it off (A/B runs).
+_WGRAD_P8 = _os.environ.get("O2M_WGRAD_P8", "1") == "1"
 
 
 def _wgrad_p8(wst) -> bool:
-    if _WGRAD_P8 is not None:
-        return _WGRAD_P8 == "1"
-    return wst is None
+    return _WGRAD_P8
 
 
 def _wgrad_stream(device):
