@@ -105,6 +105,18 @@ typedef struct {
                              for the space-to-depth form of the N = 3 image conv (a 7x7 stride-1
                              conv with 3 outputs = a 10x10 stride-4 conv with 48 outputs) */
   int32_t stats_mode;     /* what `stats` receives: O2M_STATS_MOMENTS (0) or O2M_STATS_DOT (1), below */
+  int32_t fold_pad;       /* f > 0 (bf16 only): the conv is the data gradient of a conv behind ReflectionPad2d(f)
+                             (blocks.py:17-26, builder.py:160,200): its output domain Ho x Wo is the PADDED map, and y
+                             / residual are the CROPPED map [B][Ho - 2f][Wo - 2f][Co].  Output pixel (oy, ox) is ADDED
+                             to y at (R(oy - f), R(ox - f)), R = the mirror the pad used (-i -> i, H-1+i -> H-1-i):
+                             the adjoint of the pad, without the padded gradient ever being stored or folded by a
+                             second pass.  Pixels that receive more than one contribution (rows / columns 1..f and
+                             their mirror images) are zeroed by the launch and written with packed bf16 atomic adds
+                             (run-to-run differences in the last bit there: not for the deterministic mode -- use
+                             o2m_fold_scale_dot on the padded gradient instead); all others are plain stores.
+                             `residual` is added once, by the interior contribution.  Requires act NONE, no stats,
+                             stride 1, Ho - 2f >= 2f + 2 and Wo - 2f >= 2f + 2. */
+  int32_t reserved1;      /* 0 */
   float* stats;           /* NULL, or InstanceNorm partial sums emitted by the epilogue:
                              stats[(m / R) * Co * 2 + o * 2 + {0, 1}] = sum / sum of squares of y[., o] (fp32,
                              before the rounding to `dtype`) over the R consecutive output pixels m .. m+R-1,

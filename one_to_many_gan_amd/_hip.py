@@ -33,7 +33,7 @@ ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 PAD_ZERO, PAD_REFLECT = 0, 1
 RED_L1, RED_SQ, RED_MOM = 0, 1, 2
 STATS_MOMENTS, STATS_DOT = 0, 1
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -43,7 +43,8 @@ class ConvDesc(C.Structure):
                 ("bias", _vp), ("residual", _vp),
                 ("B", _i32), ("H", _i32), ("W", _i32), ("Ci", _i32), ("Co", _i32), ("KH", _i32),
                 ("KW", _i32), ("pad", _i32), ("pad_mode", _i32), ("act", _i32), ("dtype", _i32),
-                ("w_batch_stride", _i32), ("stride", _i32), ("stats_mode", _i32), ("stats", _vp),
+                ("w_batch_stride", _i32), ("stride", _i32), ("stats_mode", _i32), ("fold_pad", _i32), ("reserved1", _i32),
+                ("stats", _vp),
                 ("deq_scale", _vp), ("aux", _vp), ("aux_scaled", _vp)]
 
 
@@ -203,14 +204,16 @@ def check(err: int, what: str):
 
 
 def conv2d_fwd(x, w, y, *, in_scale=None, out_scale=None, bias=None, residual=None, pad, pad_mode, act,
-               per_sample_w=False, stride=1, stats=None, deq=None, aux=None, aux_scaled=None):
+               per_sample_w=False, stride=1, stats=None, deq=None, aux=None, aux_scaled=None, fold_pad=0):
     """``stats``: fp32 workspace for the InstanceNorm partial sums of y (see o2m_conv_desc.stats) -- or, with
     ``aux`` (a tensor of y's shape), for the style-dot partials sum_p acc * aux (O2M_STATS_DOT); ``aux_scaled``
     then optionally receives aux * out_scale.
     ``deq``: fp8 operands (x float8_e4m3fn / float8_e5m2, w float8_e4m3fn): device tensor of the two
-    dequantisation factors."""
+    dequantisation factors.
+    ``fold_pad`` = f > 0: the conv is the data gradient behind ReflectionPad2d(f); y / residual are the CROPPED map
+    and every output pixel of the padded domain is added at its mirror image (o2m_conv_desc.fold_pad)."""
     return ops().conv2d_fwd(x, w, y, in_scale, out_scale, bias, residual, pad, pad_mode, act, per_sample_w, stride,
-                            stats, deq, aux, aux_scaled)
+                            stats, deq, aux, aux_scaled, fold_pad)
 
 
 def conv2d_dots_finalize(partial, dots, nchunks):

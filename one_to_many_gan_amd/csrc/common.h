@@ -98,6 +98,19 @@ __device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
   *reinterpret_cast<f32x4*>(p + 4) = b;
 }
 
+// 8 consecutive bf16 channels ADDED to memory: four packed atomics (global_atomic_pk_add_bf16, round to nearest even)
+__device__ __forceinline__ void atomic_add8(unsigned short* p, const float (&v)[8]) {
+  typedef short s16x2_t __attribute__((ext_vector_type(2)));
+  typedef __attribute__((address_space(1))) s16x2_t gs16x2_t;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    __builtin_amdgcn_global_atomic_fadd_v2bf16((gs16x2_t*)(p + 2 * i), __builtin_bit_cast(s16x2_t, pack_bf2(v[2 * i], v[2 * i + 1])));
+}
+__device__ __forceinline__ void atomic_add8(float* p, const float (&v)[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) unsafeAtomicAdd(p + i, v[i]);
+}
+
 // The activation code is uniform over a launch.  A per-element `switch` compiles into a chain of scalar
 // compare-and-branch blocks PER ELEMENT (with the tanh expansion in the middle): measured 8 of the 11 us
 // the p8 igemm's epilogue took.  So: ReLU / LeakyReLU / identity are one select each, driven by two

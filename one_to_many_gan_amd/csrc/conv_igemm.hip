@@ -156,6 +156,28 @@ struct RowDiv {
   }
 };
 
+// o2m_conv_desc.fold_pad = f > 0: output pixel m of the PADDED domain [B][Ho][Wo] lands on its mirror image in the
+// cropped map [B][Ho - 2f][Wo - 2f] (the adjoint of ReflectionPad2d(f)); see the header.
+struct FoldMap {
+  int f, Hc, Wc, Wo, HoWo;
+  RowDiv by_howo, by_wo;
+  __device__ FoldMap(int f_, int Ho, int Wo_, int M) : f(f_), Hc(Ho - 2 * f_), Wc(Wo_ - 2 * f_), Wo(Wo_), HoWo(Ho * Wo_),
+                                                       by_howo(Ho * Wo_, M), by_wo(Wo_, M) {}
+  // pixel index in the cropped map; interior: m is not a pad pixel; atomic: the target takes several contributions
+  __device__ __forceinline__ long pixel(int m, bool& interior, bool& atomic) const {
+    const int b = by_howo.div(m), rem = m - b * HoWo;
+    const int oy = by_wo.div(rem), ox = rem - oy * Wo;
+    const int qy = oy - f, qx = ox - f;
+    interior = (unsigned)qy < (unsigned)Hc && (unsigned)qx < (unsigned)Wc;
+    const int py = qy < 0 ? -qy : (qy >= Hc ? 2 * Hc - 2 - qy : qy);
+    const int px = qx < 0 ? -qx : (qx >= Wc ? 2 * Wc - 2 - qx : qx);
+    const bool target = (py >= 1 && py <= f) || (py >= Hc - 1 - f && py <= Hc - 2) || (px >= 1 && px <= f) ||
+                        (px >= Wc - 1 - f && px <= Wc - 2);
+    atomic = !interior || target;
+    return ((long)b * Hc + py) * Wc + px;
+  }
+};
+
 // WIDE: Ci % 64 == 0, so one 64-element stage lies inside ONE filter tap (tap-outer walk).
 // !WIDE: small Ci (image stems, Ci = 8..32): every 16-B chunk decodes its own tap.
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool IN_SCALE, bool WIDE>
@@ -548,6 +570,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
   const int wpp = d.stats ? 1 : WPP_MAX;  // wave rows per pass
   const int npass = WAVES_M / wpp;
   const int wrow_ = wave / WAVES_N;
+  const int foldp = d.fold_pad;
+  const FoldMap fmap(foldp, Ho, Wo, M);
 #pragma unroll 1
   for (int pass = 0; pass < npass; ++pass) {
     if (wrow_ / wpp == pass) {
@@ -574,7 +598,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
       const f32x4 a = *reinterpret_cast<const f32x4*>(csm + row * CSTR + ec8 * 8);
       const f32x4 b = *reinterpret_cast<const f32x4*>(csm + row * CSTR + ec8 * 8 + 4);
       float o[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-      const size_t off = (size_t)m * Co + en;
+      bool f_interior = true, f_atomic = false;
+      const size_t off = foldp ? (size_t)fmap.pixel(m, f_interior, f_atomic) * Co + en : (size_t)m * Co + en;
       float xv[8];
       if (dot_mode) {  // style dot of the data gradient: sum over pixels of (unscaled result) * aux
         load8x(AUX + off, xv, stream_out);
@@ -606,13 +631,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
         for (int q = 0; q < 8; ++q) { st[q] += o[q]; st[8 + q] += o[q] * o[q]; }
       }
       act_fwd8(o, act);
-      if (R) {
+      if (R && f_interior) {
         float rv[8];
         load8(R + off, rv);
 #pragma unroll
         for (int q = 0; q < 8; ++q) o[q] += rv[q];
       }
-      if (stream_out) store8_stream(Y + off, o);
+      if (f_atomic) atomic_add8(Y + off, o);
+      else if (stream_out) store8_stream(Y + off, o);
       else store8(Y + off, o);
     }
     if (d.stats && mbase < M) {  // (a tile's trailing passes can lie past the problem: nothing to report)
@@ -683,10 +709,6 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
   constexpr int KS = FMT ? 4 : 2;         // MFMA k-steps (32 elements each) per K-tile
   constexpr int BM = 256, BN = 256, NT = 512;
   constexpr int OPB = 32768;   // one operand of one K-tile: 256 rows x 128 B
-#ifndef O2M_P8_DIRECT_EPI
-#define O2M_P8_DIRECT_EPI 1  // (0: the LDS-staged epilogue of rounds 1-3, for A/B builds, tools/build_variant.sh)
-#endif
-  constexpr bool DIRECT = O2M_P8_DIRECT_EPI;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int H = d.H, W = d.W, Ci = d.Ci, Co = d.Co, KH = d.KH, KW = d.KW, pad = d.pad;
@@ -746,11 +768,10 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int q = b_group(j);
-    // DIRECT: LDS filter row rho = 64 wcol + 16 j + i holds output channel 64 wcol + 32 (j >> 1) + 8 (i >> 2) +
-    // 4 (j & 1) + (i & 3), so that the accumulators of one lane are 8 CONSECUTIVE channels (see the epilogue)
+    // LDS filter row rho = 64 wcol + 16 j + i holds output channel 64 wcol + 32 (j >> 1) + 8 (i >> 2) + 4 (j & 1) +
+    // (i & 3), so that the accumulators of one lane are 8 CONSECUTIVE channels (see the epilogue)
     const int rho = slot_row(q);
-    const int n = n0 + (DIRECT ? (rho & ~63) + 32 * ((rho >> 5) & 1) + 8 * ((rho >> 2) & 3) + 4 * ((rho >> 4) & 1) + (rho & 3)
-                               : rho);
+    const int n = n0 + (rho & ~63) + 32 * ((rho >> 5) & 1) + 8 * ((rho >> 2) & 3) + 4 * ((rho >> 4) & 1) + (rho & 3);
     dwoff[j] = n < Co ? (unsigned)(n * K * ES + slot_chk(q) * 16) : OOB_OFF;
   }
   unsigned aoff[4];
@@ -871,15 +892,10 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           f32x4_t& c = acc[mh * 4 + i][nh * 2 + j];
-          if constexpr (DIRECT) {  // filter rows as the A operand: a lane's 4 result registers are 4 CHANNELS of one pixel
-            if constexpr (FMT == 0) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][ks], af[i][ks], c, 0, 0, 0);
-            else if constexpr (FMT == 1) c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(bf[j][ks], af[i][ks], c, 0, 0, 0);
-            else c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(bf[j][ks], af[i][ks], c, 0, 0, 0);
-          } else {
-            if constexpr (FMT == 0) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][ks], bf[j][ks], c, 0, 0, 0);
-            else if constexpr (FMT == 1) c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(af[i][ks], bf[j][ks], c, 0, 0, 0);
-            else c = __builtin_amdgcn_mfma_f32_16x16x32_bf8_fp8(af[i][ks], bf[j][ks], c, 0, 0, 0);
-          }
+          // filter rows as the A operand: a lane's 4 result registers are 4 CHANNELS of one pixel
+          if constexpr (FMT == 0) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][ks], af[i][ks], c, 0, 0, 0);
+          else if constexpr (FMT == 1) c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(bf[j][ks], af[i][ks], c, 0, 0, 0);
+          else c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(bf[j][ks], af[i][ks], c, 0, 0, 0);
         }
     __builtin_amdgcn_s_setprio(0);
   };
@@ -936,10 +952,6 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
 #undef P8_WAIT_AND_SYNC
 #undef P8_CLOSE
   if (wrow == 0) __builtin_amdgcn_s_barrier();
-  if constexpr (!DIRECT) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the zero fills issued past the end of the reduction
-    __syncthreads();
-  }
 
   T* __restrict__ Y = static_cast<T*>(d.y);
   const T* __restrict__ R = static_cast<const T*>(d.residual);
@@ -955,188 +967,67 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
   const T* __restrict__ AUX = static_cast<const T*>(d.aux);
   T* __restrict__ AUXS = static_cast<T*>(d.aux_scaled);
 
-  if constexpr (DIRECT) {
-    // ---- epilogue straight from the accumulators -------------------------------------------------------
-    // The filter rows were the A operand and sit permuted in LDS (dwoff above), so lane l of acc[i][2h], acc[i][2h+1]
-    // holds, for pixel 16 i + (l & 15) of the wave's 128, the EIGHT consecutive channels 32 h + 8 (l >> 4) .. + 7 of
-    // the wave's 64: one 16-B vector of the output row, 64 B per pixel per store instruction.  No LDS staging, no
-    // barrier: a wave leaves as soon as its own 16 vectors per lane are out (the staged form cost two passes of
-    // 128 ds_write_b32 per lane + 4 barriers: profiles/r02, 11 of the 71 us of a tile).
-    const int g = lane >> 4, pl = lane & 15;
-    const int mwave = m0 + 128 * wrow;
-    float esc[2][8], ebias[2][8];
-    int en[2];
-    bool col_ok[2];
+  // ---- epilogue straight from the accumulators -------------------------------------------------------
+  // The filter rows were the A operand and sit permuted in LDS (dwoff above), so lane l of acc[i][2h], acc[i][2h+1]
+  // holds, for pixel 16 i + (l & 15) of the wave's 128, the EIGHT consecutive channels 32 h + 8 (l >> 4) .. + 7 of
+  // the wave's 64: one 16-B vector of the output row, 64 B per pixel per store instruction.  No LDS staging, no
+  // barrier: a wave leaves as soon as its own 16 vectors per lane are out (the staged form cost two passes of
+  // 128 ds_write_b32 per lane + 4 barriers: profiles/r02, 11 of the 71 us of a tile).
+  const int g = lane >> 4, pl = lane & 15;
+  const int mwave = m0 + 128 * wrow;
+  const int foldp = d.fold_pad;
+  const FoldMap fmap(foldp, Ho, Wo, M);
+  float esc[2][8], ebias[2][8];
+  int en[2];
+  bool col_ok[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    en[h] = n0 + 64 * wcol + 32 * h + 8 * g;
+    col_ok[h] = en[h] < Co;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { esc[h][q] = deq; ebias[h][q] = 0.f; }
+    if (col_ok[h]) {
+      if (d.out_scale && b_uniform) {
+        const float* sp = d.out_scale + (size_t)b_first * Co + en[h];
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { esc[h][q] *= s0[q]; esc[h][4 + q] *= s1[q]; }
+      }
+      if (d.bias) {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(d.bias + en[h]);
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(d.bias + en[h] + 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { ebias[h][q] = b0[q]; ebias[h][4 + q] = b1[q]; }
+      }
+    }
+  }
+  float st[2][16];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) st[h][q] = 0.f;
+  const float rdeq = 1.f / deq;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = mwave + 16 * i + pl;
+    bool f_interior = true, f_atomic = false;
+    size_t pix_fold = 0;
+    if (foldp && m < M) pix_fold = (size_t)fmap.pixel(m, f_interior, f_atomic);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      en[h] = n0 + 64 * wcol + 32 * h + 8 * g;
-      col_ok[h] = en[h] < Co;
+      if (m >= M || !col_ok[h]) continue;
+      float o[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) { esc[h][q] = deq; ebias[h][q] = 0.f; }
-      if (col_ok[h]) {
-        if (d.out_scale && b_uniform) {
-          const float* sp = d.out_scale + (size_t)b_first * Co + en[h];
-          const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 4);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) { esc[h][q] *= s0[q]; esc[h][4 + q] *= s1[q]; }
-        }
-        if (d.bias) {
-          const f32x4 b0 = *reinterpret_cast<const f32x4*>(d.bias + en[h]);
-          const f32x4 b1 = *reinterpret_cast<const f32x4*>(d.bias + en[h] + 4);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) { ebias[h][q] = b0[q]; ebias[h][4 + q] = b1[q]; }
-        }
-      }
-    }
-    float st[2][16];
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) st[h][q] = 0.f;
-    const float rdeq = 1.f / deq;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int m = mwave + 16 * i + pl;
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        if (m >= M || !col_ok[h]) continue;
-        float o[8];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { o[r] = acc[i][2 * h][r]; o[4 + r] = acc[i][2 * h + 1][r]; }
-        const size_t off = (size_t)m * Co + en[h];
-        float xv[8];
-        if (dot_mode) {  // style dot of the data gradient: sum over pixels of (unscaled result) * aux
-          load8x(AUX + off, xv, stream_out);
-#pragma unroll
-          for (int q = 0; q < 8; ++q) st[h][q] += o[q] * deq * xv[q];
-        }
-        if (d.out_scale && !b_uniform) {
-          const float* sp = d.out_scale + (size_t)(m / HoWo) * Co + en[h];
-          const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 4);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) { o[q] *= s0[q] * deq; o[4 + q] *= s1[q] * deq; }
-          if (dot_mode && AUXS) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { xv[q] *= s0[q]; xv[4 + q] *= s1[q]; }
-          }
-        } else {
-#pragma unroll
-          for (int q = 0; q < 8; ++q) o[q] *= esc[h][q];
-          if (dot_mode && AUXS && d.out_scale) {  // (a one-sample tile: esc = dequantisation x out_scale)
-#pragma unroll
-            for (int q = 0; q < 8; ++q) xv[q] *= esc[h][q] * rdeq;
-          }
-        }
-        if (dot_mode && AUXS) store8x(AUXS + off, xv, stream_out);  // aux * out_scale: the modulated input x * s
-#pragma unroll
-        for (int q = 0; q < 8; ++q) o[q] += ebias[h][q];
-        if (d.stats && !dot_mode) {
-#pragma unroll
-          for (int q = 0; q < 8; ++q) { st[h][q] += o[q]; st[h][8 + q] += o[q] * o[q]; }
-        }
-        act_fwd8(o, act);
-        if (R) {
-          float rv[8];
-          load8(R + off, rv);
-#pragma unroll
-          for (int q = 0; q < 8; ++q) o[q] += rv[q];
-        }
-#ifdef O2M_P8_NOSTORE  // (timing experiment only: how much of a tile is the output burst)
-        if (o[0] == 12345.678f)
-#endif
-        store8x(Y + off, o, stream_out);
-      }
-    }
-    if (d.stats && mwave < M) {
-      // the wave's 128 pixels x 64 channels ARE one row of the partial table: sum over the 16 lanes that share a
-      // channel vector (quad swaps, then rotations inside the row of 16), fixed order, no LDS, no atomics
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          float v = st[h][q];
-          v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
-          v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
-          v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x124, 0xf, 0xf, true));  // row_ror:4
-          v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x128, 0xf, 0xf, true));  // row_ror:8
-          st[h][q] = v;
-        }
-      if (pl == 0) {
-        const size_t part = (size_t)(mwave / 128);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          if (!col_ok[h]) continue;
-          float* sp = d.stats + (part * Co + en[h]) * 2;  // [part][channel][sum | sum of squares]
-#pragma unroll
-          for (int q = 0; q < 8; q += 2)
-            *reinterpret_cast<f32x4*>(sp + 2 * q) = f32x4{st[h][q], st[h][8 + q], st[h][q + 1], st[h][8 + q + 1]};
-        }
-      }
-    }
-    return;
-  }
-
-  // ---- epilogue: fp32 tile through LDS, whole channel vectors out (as in conv_igemm_kernel) -------------
-  constexpr int CSTR = BN + 4;
-  float* csm = reinterpret_cast<float*>(smem);
-  constexpr int VPR = BN / 8;
-  static_assert(NT % VPR == 0, "one channel vector per thread");
-  const int ec8 = tid % VPR, erow = tid / VPR, en = n0 + ec8 * 8;
-  const bool ecol_ok = en < Co;
-  float esc[8], ebias[8];  // multiplier (dequantisation x demodulation of a one-sample tile) and bias of this thread's channels
-#pragma unroll
-  for (int q = 0; q < 8; ++q) { esc[q] = deq; ebias[q] = 0.f; }
-  if (ecol_ok) {
-    if (d.out_scale && b_uniform) {
-      const float* sp = d.out_scale + (size_t)b_first * Co + en;
-      const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 4);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { esc[q] *= s0[q]; esc[4 + q] *= s1[q]; }
-    }
-    if (d.bias) {
-      const f32x4 b0 = *reinterpret_cast<const f32x4*>(d.bias + en), b1 = *reinterpret_cast<const f32x4*>(d.bias + en + 4);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { ebias[q] = b0[q]; ebias[4 + q] = b1[q]; }
-    }
-  }
-#pragma unroll 1
-  for (int pass = 0; pass < 2; ++pass) {
-    if (pass == wrow) {
-      // C/D of 16x16x32: column (channel) = lane & 15, row (pixel) = 4 (lane >> 4) + register
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            csm[(i * 16 + 4 * (lane >> 4) + r) * CSTR + wcol * 64 + j * 16 + (lane & 15)] = acc[i][j][r];
-    }
-    lds_barrier();
-    const int mbase = m0 + pass * 128;
-    float st[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) st[q] = 0.f;
-    // A thread keeps ONE 8-channel vector (NT % VPR == 0) and walks 8 rows, 16 apart: bias and (for a tile
-    // inside one sample) the demodulation scale are loaded once, ahead of the loop, and the loop is unrolled
-    // so that its LDS reads, residual loads and stores overlap.  (Measured before: the epilogue cost 11.3 of
-    // the canonical layer's 78 us -- every iteration waited for its own bias / scale loads from L2.)
-#pragma unroll 4
-    for (int it = 0; it < 128 / (NT / VPR); ++it) {
-      const int row = erow + it * (NT / VPR);
-      const int m = mbase + row;
-      if (m >= M || !ecol_ok) continue;
-      const f32x4 a = *reinterpret_cast<const f32x4*>(csm + row * CSTR + ec8 * 8);
-      const f32x4 b = *reinterpret_cast<const f32x4*>(csm + row * CSTR + ec8 * 8 + 4);
-      float o[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-      const size_t off = (size_t)m * Co + en;
+      for (int r = 0; r < 4; ++r) { o[r] = acc[i][2 * h][r]; o[4 + r] = acc[i][2 * h + 1][r]; }
+      const size_t off = (foldp ? pix_fold : (size_t)m) * Co + en[h];
       float xv[8];
       if (dot_mode) {  // style dot of the data gradient: sum over pixels of (unscaled result) * aux
         load8x(AUX + off, xv, stream_out);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) st[q] += o[q] * deq * xv[q];
+        for (int q = 0; q < 8; ++q) st[h][q] += o[q] * deq * xv[q];
       }
       if (d.out_scale && !b_uniform) {
-        const float* sp = d.out_scale + (size_t)(m / HoWo) * Co + en;
+        const float* sp = d.out_scale + (size_t)(m / HoWo) * Co + en[h];
         const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 4);
 #pragma unroll
         for (int q = 0; q < 4; ++q) { o[q] *= s0[q] * deq; o[4 + q] *= s1[q] * deq; }
@@ -1146,35 +1037,58 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
         }
       } else {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) o[q] *= esc[q];
+        for (int q = 0; q < 8; ++q) o[q] *= esc[h][q];
         if (dot_mode && AUXS && d.out_scale) {  // (a one-sample tile: esc = dequantisation x out_scale)
-          const float rdeq = 1.f / deq;
 #pragma unroll
-          for (int q = 0; q < 8; ++q) xv[q] *= esc[q] * rdeq;
+          for (int q = 0; q < 8; ++q) xv[q] *= esc[h][q] * rdeq;
         }
       }
       if (dot_mode && AUXS) store8x(AUXS + off, xv, stream_out);  // aux * out_scale: the modulated input x * s
 #pragma unroll
-      for (int q = 0; q < 8; ++q) o[q] += ebias[q];
+      for (int q = 0; q < 8; ++q) o[q] += ebias[h][q];
       if (d.stats && !dot_mode) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { st[q] += o[q]; st[8 + q] += o[q] * o[q]; }
+        for (int q = 0; q < 8; ++q) { st[h][q] += o[q]; st[h][8 + q] += o[q] * o[q]; }
       }
       act_fwd8(o, act);
-      if (R) {
+      if (R && f_interior) {
         float rv[8];
         load8(R + off, rv);
 #pragma unroll
         for (int q = 0; q < 8; ++q) o[q] += rv[q];
       }
-      store8x(Y + off, o, stream_out);
+      if (f_atomic) atomic_add8(Y + off, o);
+      else store8x(Y + off, o, stream_out);
     }
-    if (d.stats && mbase < M) stats_block_reduce<NT, VPR>(st, csm, d.stats, (long)(mbase / 128), n0, Co, tid);
-    if (pass == 0) lds_barrier();
+  }
+  if (d.stats && mwave < M) {
+    // the wave's 128 pixels x 64 channels ARE one row of the partial table: sum over the 16 lanes that share a
+    // channel vector (quad swaps, then rotations inside the row of 16), fixed order, no LDS, no atomics
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        float v = st[h][q];
+        v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+        v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+        v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x124, 0xf, 0xf, true));  // row_ror:4
+        v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x128, 0xf, 0xf, true));  // row_ror:8
+        st[h][q] = v;
+      }
+    if (pl == 0) {
+      const size_t part = (size_t)(mwave / 128);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (!col_ok[h]) continue;
+        float* sp = d.stats + (part * Co + en[h]) * 2;  // [part][channel][sum | sum of squares]
+#pragma unroll
+        for (int q = 0; q < 8; q += 2)
+          *reinterpret_cast<f32x4*>(sp + 2 * q) = f32x4{st[h][q], st[h][8 + q], st[h][q + 1], st[h][8 + q + 1]};
+      }
+    }
   }
 }
 
-// what conv_igemm_p8_kernel's fills assume (beyond the dtype and the tile count, which the callers check)
 // what conv_igemm_p8_kernel's fills assume (beyond the dtype and the tile count, which the callers check)
 inline bool p8_geometry_ok(const o2m_conv_desc& d) {
   return !d.in_scale && d.stride <= 1 && d.Ci % BK == 0 && d.KH <= 8 && d.KW <= 8 &&
@@ -1435,7 +1349,7 @@ int launch_halo(const o2m_conv_desc& d, hipStream_t s) {
 // the layers the halo-tile kernel takes (host side of its preconditions)
 inline bool halo_ok(const o2m_conv_desc& d) {
   static const int on = [] { const char* e = getenv("O2M_CONV_HALO"); return e ? atoi(e) : 1; }();
-  return on && d.dtype == O2M_BF16 && d.KH == 3 && d.KW == 3 && d.pad == 1 && d.pad_mode == O2M_PAD_ZERO && d.stride <= 1 &&
+  return on && !d.fold_pad && d.dtype == O2M_BF16 && d.KH == 3 && d.KW == 3 && d.pad == 1 && d.pad_mode == O2M_PAD_ZERO && d.stride <= 1 &&
          !d.in_scale && d.Ci % 64 == 0 && (d.Co == 64 || d.Co == 128) && d.W % 32 == 0 && d.H % 8 == 0 &&
          (long)d.B * (d.H / 8) * (d.W / 32) >= 2 * kFillBlocks;
 }
@@ -1562,6 +1476,33 @@ extern "C" int32_t o2m_conv2d_stats_rows(const o2m_conv_desc* d) {
   return (r > 0 && howo > 0 && howo % r == 0) ? r : 0;
 }
 
+namespace {
+// fold_pad: the pixels of the cropped map that take more than one contribution (rows / columns 1..f and Hc-1-f..Hc-2)
+// start from zero; one thread per (strip pixel, 16-B channel vector).  Strip pixels are enumerated as 2f whole rows +
+// 2f columns of the remaining rows (the overlap is written twice with the same zero).
+__global__ __launch_bounds__(256) void fold_zero_kernel(unsigned short* __restrict__ y, int B, int Hc, int Wc, int C, int f) {
+  const int CV = C / 8;
+  const long per_img = (long)2 * f * Wc + (long)2 * f * Hc;
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long)B * per_img * CV) return;
+  const int cv = (int)(t % CV);
+  const long pi = t / CV;
+  const int b = (int)(pi / per_img);
+  int k = (int)(pi - (long)b * per_img), py, px;
+  if (k < 2 * f * Wc) {
+    const int r = k / Wc;
+    px = k - r * Wc;
+    py = r < f ? 1 + r : Hc - 1 - f + (r - f);
+  } else {
+    k -= 2 * f * Wc;
+    const int c = k / Hc;
+    py = k - c * Hc;
+    px = c < f ? 1 + c : Wc - 1 - f + (c - f);
+  }
+  *reinterpret_cast<u32x4*>(y + (((size_t)b * Hc + py) * Wc + px) * C + cv * 8) = u32x4{0u, 0u, 0u, 0u};
+}
+}  // namespace
+
 extern "C" int o2m_conv2d_fwd(const o2m_conv_desc* d, void* stream) {
   if (!d || !d->x || !d->w || !d->y) return O2M_ERR_BAD_ARG;
   if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Ci <= 0 || d->Co <= 0) return O2M_ERR_BAD_ARG;
@@ -1577,6 +1518,19 @@ extern "C" int o2m_conv2d_fwd(const o2m_conv_desc* d, void* stream) {
   // slices of the batch -- every sample's rows are independent, so the result is that of one launch.
   const long x_sample = (long)d->H * d->W * (long)d->Ci * esz;
   if (x_sample > 0x7fffffffL) return O2M_ERR_UNSUPPORTED;
+  if (d->fold_pad < 0 || d->reserved1 != 0) return O2M_ERR_BAD_ARG;
+  if (d->fold_pad > 0) {  // data gradient of a reflection-padded conv, folded in the epilogue (header)
+    const int f = d->fold_pad, Ho = d->H + 2 * d->pad - d->KH + 1, Wo = d->W + 2 * d->pad - d->KW + 1;
+    if (d->dtype != O2M_BF16 || d->act != O2M_ACT_NONE || d->stats || d->aux || d->stride > 1 || d->w_batch_stride > 0)
+      return O2M_ERR_BAD_ARG;
+    if (Ho - 2 * f < 2 * f + 2 || Wo - 2 * f < 2 * f + 2) return O2M_ERR_BAD_ARG;
+    if ((long)d->B * x_sample > 0x7fffffffL) return O2M_ERR_UNSUPPORTED;  // (no batch slicing in this form)
+    const int Hc = Ho - 2 * f, Wc = Wo - 2 * f;
+    const long n = (long)d->B * (2L * f * Wc + 2L * f * Hc) * (d->Co / 8);
+    hipLaunchKernelGGL(fold_zero_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<unsigned short*>(d->y), d->B, Hc, Wc, d->Co, f);
+    O2M_LAUNCH_CHECK();
+  }
   if ((long)d->B * x_sample > 0x7fffffffL) {
     const int S_ = d->stride > 1 ? d->stride : 1;
     const long howo = (long)((d->H + 2 * d->pad - d->KH) / S_ + 1) * ((d->W + 2 * d->pad - d->KW) / S_ + 1);

@@ -474,6 +474,30 @@ __global__ __launch_bounds__(NT) void resample_kernel(const T* x, T* y, const in
   }
 }
 
+template <typename T> struct RawVec;  // 8 consecutive channels as loaded (unpacked to floats on use)
+template <> struct RawVec<unsigned short> {
+  u32x4 v;
+  __device__ __forceinline__ void load(const unsigned short* p) { v = *reinterpret_cast<const u32x4*>(p); }
+  __device__ __forceinline__ void unpack(float (&f)[8]) const {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f[2 * i] = __builtin_bit_cast(float, v[i] << 16);
+      f[2 * i + 1] = __builtin_bit_cast(float, v[i] & 0xffff0000u);
+    }
+  }
+};
+template <> struct RawVec<float> {
+  f32x4 a, b;
+  __device__ __forceinline__ void load(const float* p) {
+    a = *reinterpret_cast<const f32x4*>(p);
+    b = *reinterpret_cast<const f32x4*>(p + 4);
+  }
+  __device__ __forceinline__ void unpack(float (&f)[8]) const {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[i] = a[i]; f[4 + i] = b[i]; }
+  }
+};
+
 // 2x2 outputs per thread from ONE (TY+SY) x (TX+SX) input patch: neighbouring outputs of a banded
 // operator start at most SPAN source pixels apart (host-checked), so their taps overlap and the
 // per-output TN^2 loads (L1-bandwidth-bound: 36 x 16 B per output for the transposed upsample)
@@ -484,8 +508,11 @@ __global__ __launch_bounds__(NT) void resample_kernel(const T* x, T* y, const in
 // conv -> InstanceNorm -> (Leaky)ReLU -> DownSample chains of the encoder and of the discriminator / style extractor
 // (builder.py:170-173,272-282) without the normalised map ever being written: it is not needed by the backward
 // pass either (InstanceNorm differentiates through x and the statistics, the activation mask is the sign of xh).
+#ifndef O2M_RS_WAVES
+#define O2M_RS_WAVES 3  // waves per SIMD the register allocation must leave room for (A/B: tools/build_variant.sh)
+#endif
 template <typename T, int TY, int TX, int SY, int SX, bool NORM = false>
-__global__ __launch_bounds__(NT) void resample2x2_kernel(const T* __restrict__ x, T* __restrict__ y,
+__global__ __launch_bounds__(NT, O2M_RS_WAVES) void resample2x2_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                          const int* __restrict__ sy,
                                                          const float* __restrict__ wy,
                                                          const int* __restrict__ sx,
@@ -532,30 +559,68 @@ __global__ __launch_bounds__(NT) void resample2x2_kernel(const T* __restrict__ x
     for (int c = 0; c < 2; ++c)
 #pragma unroll
       for (int i = 0; i < 8; ++i) acc[a][c][i] = 0.f;
+  if constexpr (!NORM) {
 #pragma unroll
-  for (int r = 0; r < PY; ++r) {
-    const int iy = min(y0 + r, H - 1);
-    float h0[8], h1[8];
+    for (int r = 0; r < PY; ++r) {
+      const int iy = min(y0 + r, H - 1);
+      float h0[8], h1[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) h0[i] = h1[i] = 0.f;
+      for (int i = 0; i < 8; ++i) h0[i] = h1[i] = 0.f;
 #pragma unroll
-    for (int k = 0; k < PX; ++k) {
-      const int ix = min(x0 + k, W - 1);
-      float v[8];
-      load8(base + ((size_t)iy * W + ix) * C, v);
-      if constexpr (NORM) {
+      for (int k = 0; k < PX; ++k) {
+        const int ix = min(x0 + k, W - 1);
+        float v[8];
+        load8(base + ((size_t)iy * W + ix) * C, v);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = act_fwd_piecewise((v[i] - mu[i]) * rs[i], relu, neg);
+        for (int i = 0; i < 8; ++i) { h0[i] += cx[0][k] * v[i]; h1[i] += cx[1][k] * v[i]; }
       }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { h0[i] += cx[0][k] * v[i]; h1[i] += cx[1][k] * v[i]; }
+      for (int i = 0; i < 8; ++i) {
+        acc[0][0][i] += cy[0][r] * h0[i];
+        acc[0][1][i] += cy[0][r] * h1[i];
+        acc[1][0][i] += cy[1][r] * h0[i];
+        acc[1][1][i] += cy[1][r] * h1[i];
+      }
     }
+  } else {
+    // The patch rows are fetched in groups of RG rows, all loads of a group issued before its first use: a row's
+    // arithmetic is ~0.5 us, an HBM round trip ~2 us, and with the loads issued row by row a wave paid that latency
+    // PY times over (this form ran at 2.1 TB/s; 132 VGPRs = 3 waves per SIMD do not hide it).  The empty asm between
+    // groups keeps the compiler from hoisting every load of the patch to the top (258 VGPRs, one wave per SIMD).
+    constexpr int RG = PY % 3 == 0 ? 3 : (PY % 2 == 0 ? 2 : 1);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      acc[0][0][i] += cy[0][r] * h0[i];
-      acc[0][1][i] += cy[0][r] * h1[i];
-      acc[1][0][i] += cy[1][r] * h0[i];
-      acc[1][1][i] += cy[1][r] * h1[i];
+    for (int r0 = 0; r0 < PY; r0 += RG) {
+      RawVec<T> raw[RG][PX];
+#pragma unroll
+      for (int rr = 0; rr < RG; ++rr) {
+        const int iy = min(y0 + r0 + rr, H - 1);
+#pragma unroll
+        for (int k = 0; k < PX; ++k) raw[rr][k].load(base + ((size_t)iy * W + min(x0 + k, W - 1)) * C);
+      }
+#pragma unroll
+      for (int rr = 0; rr < RG; ++rr) {
+        const int r = r0 + rr;
+        float h0[8], h1[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) h0[i] = h1[i] = 0.f;
+#pragma unroll
+        for (int k = 0; k < PX; ++k) {
+          float v[8];
+          raw[rr][k].unpack(v);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] = act_fwd_piecewise((v[i] - mu[i]) * rs[i], relu, neg);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { h0[i] += cx[0][k] * v[i]; h1[i] += cx[1][k] * v[i]; }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          acc[0][0][i] += cy[0][r] * h0[i];
+          acc[0][1][i] += cy[0][r] * h1[i];
+          acc[1][0][i] += cy[1][r] * h0[i];
+          acc[1][1][i] += cy[1][r] * h1[i];
+        }
+      }
+      asm volatile("" ::: "memory");
     }
   }
   T* o00 = y + (((size_t)b * Ho + oy0) * Wo + ox0) * C + cv * 8;
@@ -577,30 +642,6 @@ __global__ __launch_bounds__(NT) void resample2x2_kernel(const T* __restrict__ x
 // two 1-D passes this replaces moved the intermediate map through HBM and ran their row walk at ~2 TB/s.
 // The vertical weights are block-uniform: re-indexed on the patch rows (zero outside an output's band) they
 // sit in SGPRs and the row walk has only static register indices.
-template <typename T> struct RawVec;  // 8 consecutive channels as loaded (unpacked to floats on use)
-template <> struct RawVec<unsigned short> {
-  u32x4 v;
-  __device__ __forceinline__ void load(const unsigned short* p) { v = *reinterpret_cast<const u32x4*>(p); }
-  __device__ __forceinline__ void unpack(float (&f)[8]) const {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      f[2 * i] = __builtin_bit_cast(float, v[i] << 16);
-      f[2 * i + 1] = __builtin_bit_cast(float, v[i] & 0xffff0000u);
-    }
-  }
-};
-template <> struct RawVec<float> {
-  f32x4 a, b;
-  __device__ __forceinline__ void load(const float* p) {
-    a = *reinterpret_cast<const f32x4*>(p);
-    b = *reinterpret_cast<const f32x4*>(p + 4);
-  }
-  __device__ __forceinline__ void unpack(float (&f)[8]) const {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { f[i] = a[i]; f[4 + i] = b[i]; }
-  }
-};
-
 template <typename T, int TY, int TX, int SY, int SX, int OH, int OW>
 __global__ __launch_bounds__(NT) void resample_tile_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                            const int* __restrict__ sy, const float* __restrict__ wy,
@@ -1048,7 +1089,7 @@ void close(int slot, hipStream_t s) {
 
 extern "C" {
 
-int o2m_abi_version(void) { return 18; }
+int o2m_abi_version(void) { return 19; }
 
 int32_t o2m_launch_timing(int32_t enable) {
   std::lock_guard<std::mutex> lock(o2m_timing::g_mu);

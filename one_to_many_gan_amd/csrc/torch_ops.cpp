@@ -92,7 +92,7 @@ inline void done(int err, const char* op, bool meta) {
 void conv2d_fwd(const Tensor& x, const Tensor& w, Tensor& y, const OptT& in_scale, const OptT& out_scale,
                 const OptT& bias, const OptT& residual, int64_t pad, int64_t pad_mode, int64_t act,
                 bool per_sample_w, int64_t stride, const std::optional<Tensor>& stats, const OptT& deq, const OptT& aux,
-                const std::optional<Tensor>& aux_scaled) {
+                const std::optional<Tensor>& aux_scaled, int64_t fold_pad) {
   const char* op = "o2m::conv2d_fwd";
   chk_f32(stats, op, "stats"); chk_f32(deq, op, "deq"); chk(aux, op, "aux"); chk(aux_scaled, op, "aux_scaled");
   const bool f8 = is_fp8(x);
@@ -115,8 +115,10 @@ void conv2d_fwd(const Tensor& x, const Tensor& w, Tensor& y, const OptT& in_scal
   TORCH_CHECK(!per_sample_w || w.size(0) == x.size(0), op, ": per-sample filters need one filter per sample");
   const int64_t s = stride > 1 ? stride : 1;
   const int64_t Ho = (x.size(1) + 2 * pad - KH) / s + 1, Wo = (x.size(2) + 2 * pad - KW) / s + 1;
-  TORCH_CHECK(y.size(0) == x.size(0) && y.size(1) == Ho && y.size(2) == Wo && y.size(3) == Co, op,
-              ": y must be [", x.size(0), ", ", Ho, ", ", Wo, ", ", Co, "], got ", y.sizes());
+  TORCH_CHECK(fold_pad >= 0 && 2 * fold_pad < Ho && 2 * fold_pad < Wo, op, ": fold_pad out of range");
+  const int64_t Hy = Ho - 2 * fold_pad, Wy = Wo - 2 * fold_pad;  // fold_pad: y is the cropped map (o2m_conv_desc.fold_pad)
+  TORCH_CHECK(y.size(0) == x.size(0) && y.size(1) == Hy && y.size(2) == Wy && y.size(3) == Co, op,
+              ": y must be [", x.size(0), ", ", Hy, ", ", Wy, ", ", Co, "], got ", y.sizes());
   TORCH_CHECK(!residual.has_value() || residual->sizes() == y.sizes(), op, ": residual must have y's shape");
   TORCH_CHECK(!in_scale.has_value() || (in_scale->size(0) == x.size(0) && in_scale->size(-1) == x.size(3)), op, ": in_scale is [B][Ci]");
   TORCH_CHECK(!out_scale.has_value() || (out_scale->size(0) == x.size(0) && out_scale->size(-1) == Co), op, ": out_scale is [B][Co]");
@@ -131,6 +133,7 @@ void conv2d_fwd(const Tensor& x, const Tensor& w, Tensor& y, const OptT& in_scal
   d.deq_scale = fptr(deq);
   d.w_batch_stride = per_sample_w ? i32(Co * KH * KW * x.size(3), op) : 0;
   d.stride = i32(stride, op);
+  d.fold_pad = i32(fold_pad, op);
   if (stats.has_value()) {
     const int rows = o2m_conv2d_stats_rows(&d);
     TORCH_CHECK(rows > 0, op, ": this conv cannot emit InstanceNorm partials (Ho*Wo is not a multiple of its row block)");
@@ -590,7 +593,7 @@ TORCH_LIBRARY(o2m, m) {
   m.def("reduce_blocks(int n) -> int", &reduce_blocks);
   m.def("conv2d_fwd(Tensor x, Tensor w, Tensor(a!) y, Tensor? in_scale, Tensor? out_scale, Tensor? bias, Tensor? residual, "
         "int pad, int pad_mode, int act, bool per_sample_w, int stride, Tensor(b!)? stats=None, Tensor? deq=None, Tensor? aux=None, "
-        "Tensor(c!)? aux_scaled=None) -> ()");
+        "Tensor(c!)? aux_scaled=None, int fold_pad=0) -> ()");
   m.def("conv2d_dots_finalize(Tensor partial, Tensor(a!) dots, int nchunks) -> ()");
   m.def("amax(Tensor x, Tensor(a!) amax) -> ()");
   m.def("quantize_fp8(Tensor x, Tensor amax, Tensor(a!) y, Tensor(b!) deq) -> ()");

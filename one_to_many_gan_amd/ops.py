@@ -810,6 +810,15 @@ class _ConvFn(torch.autograd.Function):
                              stats=part, aux=x, aux_scaled=xs)
                 dots = torch.empty((B, cip), dtype=torch.float32, device=dev)
                 H.conv2d_dots_finalize(part, dots, nchunks)
+            elif (_FOLD_EPILOGUE and s is None and pad_mode == H.PAD_REFLECT and g.dtype == torch.bfloat16
+                  and not deterministic() and not prep.fp8_ok(True, B * hp * wp)
+                  and min(Hh, Ww) >= 2 * pad + 2):
+                # plain conv behind ReflectionPad2d (the encoder's residual blocks, the image stem / head): the GEMM's
+                # epilogue adds every pixel of the padded domain at its mirror image of g_x (o2m_conv_desc.fold_pad)
+                # and the block's residual gradient with it -- no padded gradient, no fold pass
+                g_x = torch.empty_like(x)
+                H.conv2d_fwd(gu, w_d, g_x, pad=kpad, pad_mode=H.PAD_ZERO, act=H.ACT_NONE, residual=res_in, fold_pad=pad)
+                res_in = None
             else:
                 gxp = torch.empty((B, hp, wp, cip), dtype=g.dtype, device=dev)
                 if prep.fp8_ok(True, B * hp * wp):  # e5m2 gradients x e4m3 filter
@@ -1061,6 +1070,10 @@ class _SplitBatchFn(torch.autograd.Function):
 def split_batch(t, k):
     return _SplitBatchFn.apply(t, k)
 
+
+# O2M_FOLD_EPILOGUE=0: the data gradient of a reflection-padded plain conv as padded GEMM output + fold pass (rounds 1-3;
+# always so in deterministic mode: the epilogue form adds the mirrored rows / columns with bf16 atomics)
+_FOLD_EPILOGUE = _os.environ.get("O2M_FOLD_EPILOGUE", "1") == "1"
 
 # O2M_FUSED_NORM_DOWN=0: InstanceNorm + activation and the DownSample behind it as two passes (round-2 form)
 _FUSED_NORM_DOWN = _os.environ.get("O2M_FUSED_NORM_DOWN", "1") == "1"

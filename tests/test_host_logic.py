@@ -38,7 +38,7 @@ def test_library_loads_and_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     from one_to_many_gan_amd import _hip
 
-    assert ctypes.sizeof(_hip.ConvDesc) == 7 * 8 + 14 * 4 + 4 * 8  # 7 pointers, 13 ints + stats_mode, stats, deq_scale, aux, aux_scaled
+    assert ctypes.sizeof(_hip.ConvDesc) == 7 * 8 + 16 * 4 + 4 * 8  # 7 pointers, 13 ints + stats_mode, fold_pad, reserved1; stats, deq_scale, aux, aux_scaled
     assert ctypes.sizeof(_hip.WgradDesc) == 5 * 8 + 14 * 4 + 8  # 5 pointers, 14 ints, slabs
     assert ctypes.sizeof(_hip.PrepJob) == 6 * 8 + 8 * 4  # o2m_prep_job: 6 pointers, 5 ints, c, first_block, reserved
 

@@ -777,3 +777,48 @@ def test_fused_instance_norm_activation_downsample_matches_the_two_passes(dt):
             assert float((xa.grad.float() - xb.grad.float()).norm() / xa.grad.float().norm()) < (2e-5 if dt == torch.float32 else 3e-2)
     finally:
         pk.set_precision("bf16")
+
+
+@pytest.mark.parametrize("case", [
+    (16, 64, 64, 256, 256, 3, 1, True),    # p8 kernel (256 tiles) + 128x128 tail tiles, with the residual gradient
+    (32, 64, 64, 256, 256, 3, 1, False),   # two rounds of p8 tiles + tail
+    (3, 24, 40, 64, 128, 3, 1, True),      # generic tiles, non-square map
+    (4, 40, 48, 8, 64, 7, 3, True),        # the image head's 7 x 7 (Ci = 8: the narrow-reduction loader), pad 3
+], ids=["p8+tail", "p8x2", "generic", "7x7pad3"])
+def test_reflect_fold_in_the_conv_epilogue_matches_the_fold_pass(case):
+    """o2m_conv_desc.fold_pad: the data gradient of a conv behind ReflectionPad2d(f), folded by the GEMM's epilogue
+    (plain stores + packed bf16 atomic adds on the mirrored rows / columns) against the two-pass form it replaces
+    (padded GEMM output + o2m_fold_scale_dot, itself checked against torch above).  Both round to bf16 -- the fold
+    pass once from an fp32 sum of bf16-rounded terms, the epilogue after every atomic add -- so pixels with several
+    contributions may differ by a couple of bf16 steps; everything else must agree exactly (to one rounding of the
+    residual sum where a residual is added)."""
+    from one_to_many_gan_amd import _hip as H
+
+    B, Hh, Ww, Cg, Cx, k, f, with_res = case
+    torch.manual_seed(5)
+    dev, dt = "cuda", torch.bfloat16
+    g = torch.randn(B, Hh, Ww, Cg, device=dev).to(dt)                 # gradient of the conv output
+    w = (torch.randn(Cx, k, k, Cg, device=dev) / (Cg * k * k) ** 0.5).to(dt)   # flipped / transposed filter
+    res = torch.randn(B, Hh, Ww, Cx, device=dev).to(dt) if with_res else None
+    kpad = k - 1
+    hp, wp = Hh + 2 * f, Ww + 2 * f
+    gpad = torch.empty(B, hp, wp, Cx, device=dev, dtype=dt)
+    H.conv2d_fwd(g, w, gpad, pad=kpad, pad_mode=H.PAD_ZERO, act=H.ACT_NONE)
+    want = torch.empty(B, Hh, Ww, Cx, device=dev, dtype=dt)
+    H.fold_scale_dot(gpad, None, None, want, None, f, gres=res)
+    got = torch.full((B, Hh, Ww, Cx), float("nan"), device=dev, dtype=dt)
+    H.conv2d_fwd(g, w, got, pad=kpad, pad_mode=H.PAD_ZERO, act=H.ACT_NONE, residual=res, fold_pad=f)
+    torch.cuda.synchronize()
+    assert torch.isfinite(got.float()).all()
+    single = torch.ones(Hh, Ww, dtype=torch.bool, device=dev)   # pixels with exactly one contribution
+    for lo, hi in ((1, f), ):
+        single[lo:hi + 1, :] = False; single[Hh - 1 - f:Hh - 1, :] = False
+        single[:, lo:hi + 1] = False; single[:, Ww - 1 - f:Ww - 1] = False
+    if with_res:  # (the fold pass adds the residual to the bf16-ROUNDED padded gradient, the epilogue to the fp32 sum)
+        a1, b1 = got[:, single].float(), want[:, single].float()
+        assert float((a1 - b1).abs().max()) <= 2.0 ** -7 * float(b1.abs().max())
+    else:
+        assert torch.equal(got[:, single], want[:, single])
+    a, b = got[:, ~single].float(), want[:, ~single].float()
+    assert float((a - b).abs().max()) <= 2.0 ** -6 * float(b.abs().max())
+    assert float((a - b).norm() / b.norm()) < 4e-3
