@@ -105,6 +105,7 @@ SIGNATURES = {
     "o2m_reduce_blocks": (_i32, [_i64]),
     "o2m_reduce_fwd": (_i32, [_vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp]),
     "o2m_reduce_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp]),
+    "o2m_pair_grad": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp]),
     "o2m_adam_step": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _vp]),
 }
 
@@ -404,6 +405,11 @@ def reduce_fwd(a, b, w, partials, mode):
 
 def reduce_bwd(a, b, w, coef, ga, mode):
     ops().reduce_bwd(a, b, w, coef, ga, mode)
+
+
+def pair_grad(a, b, w, coef, gin_a, gin_b, ga, gb):
+    """ga = gin_a + coef * w[b] * (a - b), gb = gin_b - coef * w[b] * (a - b) in one pass (o2m_pair_grad)."""
+    ops().pair_grad(a, b, w, coef, gin_a, gin_b, ga, gb)
 
 
 def adam_step(p, g, m, v, step, lr, beta1, beta2, eps, grad_scale):

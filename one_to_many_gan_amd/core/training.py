@@ -199,6 +199,8 @@ def discriminator_step(config, device, discriminator, generator, mapping_network
 
 
 
+# O2M_PATH_TAP=0: path-loss terms from the collected feature maps after the pass (two consumers per map: autograd adds)
+_PATH_TAP = os.environ.get("O2M_PATH_TAP", "1") == "1"
 _BATCH_DECODES = os.environ.get("O2M_BATCH_DECODES", "1") == "1"
 # O2M_SIDE_STYLE=0: both style-extractor passes of generator_step on the main stream (A/B of running them beside the
 # encoder / the discriminator on the second stream)
@@ -258,7 +260,10 @@ def _batched_decodes(config, device, generator, discriminator, mapping_network, 
     w_ext = torch.cat([w1, w2], dim=1)
 
     def extraction_group():
-        feats = generator._decode(ops.batch_gather(t_lat, batch, (0, 0)), w_ext, collect=True, internal=True)
+        # the path-loss term of every feature map is taken as the map passes (ops.halves_sq_tap)
+        inv_h2 = (1.0 / (h.float() ** 2)).contiguous()
+        feats = generator._decode(ops.batch_gather(t_lat, batch, (0, 0)), w_ext, collect=True, internal=True,
+                                  tap=inv_h2 if _PATH_TAP else None)
         return path_loss_halves(feats, h)
 
     if side is not None:

@@ -855,6 +855,31 @@ __global__ __launch_bounds__(NT) void reduce_bwd_kernel(const T* a, const T* b, 
   }
 }
 
+template <typename T>
+__global__ __launch_bounds__(NT) void pair_grad_kernel(const T* a, const T* b, const float* w, const float* coef,
+                                                       const T* gin_a, const T* gin_b, T* ga, T* gb, long nps_vec,
+                                                       long nvec) {
+  const float c0 = coef[0];
+  for (long v = (long)blockIdx.x * NT + threadIdx.x; v < nvec; v += (long)gridDim.x * NT) {
+    float av[8], bv[8], ia[8], ib[8];
+    load8(a + (size_t)v * 8, av);
+    load8(b + (size_t)v * 8, bv);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ia[i] = ib[i] = 0.f;
+    if (gin_a) load8(gin_a + (size_t)v * 8, ia);
+    if (gin_b) load8(gin_b + (size_t)v * 8, ib);
+    const float ws = c0 * (w ? w[v / nps_vec] : 1.f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float t = ws * (av[i] - bv[i]);
+      ia[i] += t;
+      ib[i] -= t;
+    }
+    store8(ga + (size_t)v * 8, ia);
+    store8(gb + (size_t)v * 8, ib);
+  }
+}
+
 // ---- per-sample modulated filters ---------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(NT) void modulate_weights_kernel(const float* w32, const float* s, T* out,
@@ -1503,6 +1528,17 @@ int o2m_reduce_bwd(const void* a, const void* b, const float* w, const float* co
   DISPATCH_T(dtype, hipLaunchKernelGGL(reduce_bwd_kernel<T>, dim3(grid_for(nvec)), dim3(NT), 0, s,
                                        (const T*)a, (const T*)b, w, coef, (T*)ga,
                                        (long)(n_per_sample / 8), nvec, mode));
+  O2M_LAUNCH_CHECK();
+  return 0;
+}
+
+int o2m_pair_grad(const void* a, const void* b, const float* w, const float* coef, const void* gin_a, const void* gin_b,
+                  void* ga, void* gb, int32_t B, int64_t n_per_sample, int32_t dtype, void* stream) {
+  if (!a || !b || !coef || !ga || !gb || B <= 0 || n_per_sample <= 0 || (n_per_sample & 7)) return O2M_ERR_BAD_ARG;
+  const long nvec = (long)B * n_per_sample / 8;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(pair_grad_kernel<T>, dim3(grid_for(nvec)), dim3(NT), 0, s, (const T*)a, (const T*)b, w,
+                                       coef, (const T*)gin_a, (const T*)gin_b, (T*)ga, (T*)gb, (long)(n_per_sample / 8), nvec));
   O2M_LAUNCH_CHECK();
   return 0;
 }

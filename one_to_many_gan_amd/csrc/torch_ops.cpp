@@ -573,6 +573,21 @@ void reduce_bwd(const Tensor& a, const OptT& b, const OptT& w, const Tensor& coe
                                 dt_a, stream));
 }
 
+void pair_grad(const Tensor& a, const Tensor& b, const OptT& w, const Tensor& coef, const OptT& gin_a, const OptT& gin_b, Tensor& ga,
+               Tensor& gb) {
+  const char* op = "o2m::pair_grad";
+  chk(a, op, "a"); chk(b, op, "b"); chk_f32(w, op, "w"); chk_f32(coef, op, "coef"); chk(gin_a, op, "gin_a"); chk(gin_b, op, "gin_b");
+  chk(ga, op, "ga"); chk(gb, op, "gb");
+  same_dtype(a, b, op, "a", "b"); same_dtype(a, ga, op, "a", "ga"); same_dtype(a, gb, op, "a", "gb");
+  same_dtype(a, gin_a, op, "a", "gin_a"); same_dtype(a, gin_b, op, "a", "gin_b");
+  TORCH_CHECK(b.sizes() == a.sizes() && ga.sizes() == a.sizes() && gb.sizes() == a.sizes() &&
+                  (!gin_a.has_value() || gin_a->sizes() == a.sizes()) && (!gin_b.has_value() || gin_b->sizes() == a.sizes()),
+              op, ": a, b, gin_a, gin_b, ga, gb share one shape");
+  TORCH_CHECK(coef.numel() >= 1 && (!w.has_value() || w->numel() >= a.size(0)), op, ": coef is one scalar, w one weight per sample");
+  O2M_CALL(op, a, o2m_pair_grad(ptr(a), ptr(b), fptr(w), ptr<float>(coef), ptr(gin_a), ptr(gin_b), ptr(ga), ptr(gb), i32(a.size(0), op),
+                               a.numel() / a.size(0), dtype_code(a, op), stream));
+}
+
 void adam_step(Tensor& p, const Tensor& g, Tensor& m, Tensor& v, const Tensor& step, double lr, double beta1, double beta2, double eps,
                double grad_scale) {
   const char* op = "o2m::adam_step";
@@ -631,6 +646,7 @@ TORCH_LIBRARY(o2m, m) {
   m.def("unpack_nhwc(Tensor src, Tensor(a!) dst) -> ()");
   m.def("reduce_fwd(Tensor a, Tensor? b, Tensor? w, Tensor(a!) partials, int mode) -> ()");
   m.def("reduce_bwd(Tensor a, Tensor? b, Tensor? w, Tensor coef, Tensor(a!) ga, int mode) -> ()");
+  m.def("pair_grad(Tensor a, Tensor b, Tensor? w, Tensor coef, Tensor? gin_a, Tensor? gin_b, Tensor(a!) ga, Tensor(b!) gb) -> ()");
   m.def("adam_step(Tensor(a!) p, Tensor g, Tensor(b!) m, Tensor(c!) v, Tensor step, float lr, float beta1, float beta2, float eps, "
         "float grad_scale) -> ()");
 }
@@ -669,6 +685,7 @@ TORCH_LIBRARY(o2m, m) {
   m.impl("unpack_nhwc", &unpack_nhwc);            \
   m.impl("reduce_fwd", &reduce_fwd);              \
   m.impl("reduce_bwd", &reduce_bwd);              \
+  m.impl("pair_grad", &pair_grad);                \
   m.impl("adam_step", &adam_step);
 
 TORCH_LIBRARY_IMPL(o2m, CUDA, m) { O2M_IMPLS(m) }

@@ -118,9 +118,11 @@ class Generator(nn.Module):
                 k += 1
         return t
 
-    def _decode(self, t, w, collect: bool, internal: bool = False):
+    def _decode(self, t, w, collect: bool, internal: bool = False, tap=None):
         """``internal``: hand back NHWC buffers instead of public views (core/training.py runs several
-        decodes as one batch and splits the result itself)."""
+        decodes as one batch and splits the result itself).  ``tap`` (with ``collect`` and ``internal``): per-sample
+        weights of the path-loss pair term; the collected entries are then (term, channels, map shape) with the term
+        taken as the map passes (ops.halves_sq_tap) instead of the maps themselves."""
         feats, i = [], 0
         # one UnbindBackward (a single stack) instead of a zeros + copy + accumulate trio per style block
         w = w.unbind(0)
@@ -145,7 +147,11 @@ class Generator(nn.Module):
             i += 1
             if collect:
                 c = m.out_features if isinstance(m, Conv2dWeightModulate) else m.dim
-                feats.append((t, c) if internal else ops.to_public(t, c))
+                if tap is not None and internal:
+                    t, term = ops.halves_sq_tap(t, tap)
+                    feats.append((term, c, tuple(t.shape)))
+                else:
+                    feats.append((t, c) if internal else ops.to_public(t, c))
                 if i == self.n_style_blocks:
                     return feats
         raise ValueError("No return layers specified.")

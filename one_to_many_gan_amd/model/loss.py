@@ -87,7 +87,12 @@ def path_loss_halves(features, cent_fin_diff_h: torch.Tensor) -> torch.Tensor:
     loss.py:98-111); padded channels are zero in both halves and do not count in the mean."""
     inv_h2 = (1.0 / (cent_fin_diff_h.float() ** 2)).contiguous()
     total = torch.zeros((), device=features[0][0].device)
-    for t, c in features:
-        b2, hh, ww, _ = t.shape
-        total = total + ops.halves_sq_sum(t, inv_h2) / (b2 // 2 * c * hh * ww)
+    for entry in features:
+        if len(entry) == 3:  # (pair term taken while the map passed, channels, shape): Generator._decode(tap=...)
+            term, c, (b2, hh, ww, _) = entry
+        else:
+            t, c = entry
+            b2, hh, ww, _ = t.shape
+            term = ops.halves_sq_sum(t, inv_h2)
+        total = total + term / (b2 // 2 * c * hh * ww)
     return total / len(features)

@@ -1243,6 +1243,40 @@ def halves_sq_sum(t, w):
     return _HalvesSqFn.apply(t, w)
 
 
+class _HalvesTapFn(torch.autograd.Function):
+    """(t, sum_b w[b] * sum (t[b] - t[b + n])^2): the path-loss term of a decoder feature map that ALSO goes on to
+    the next decoder layer (loss.py:98-111 on the maps Generator.extract returns, builder.py:226-253).  Taking the map
+    THROUGH this function makes it the map's only consumer, so backward sees the next layer's gradient and the term's
+    upstream scalar together and forms the map's gradient in one pass (o2m_pair_grad) -- instead of reduce_bwd + a
+    negation pass for the second half + autograd's accumulation add of two activation-sized tensors."""
+
+    @staticmethod
+    def forward(ctx, t, w):
+        n = t.shape[0] // 2
+        part = _partials(t[:n].numel(), 1, t.device)
+        H.reduce_fwd(t[:n], t[n:], w, part, H.RED_SQ)
+        ctx.save_for_backward(t, w)
+        return t.view_as(t), part.sum()
+
+    @staticmethod
+    def backward(ctx, g_t, g_s):
+        t, w = ctx.saved_tensors
+        n = t.shape[0] // 2
+        if g_s is None:  # the term is unused: pass the map's gradient through
+            return g_t, None
+        coef = (g_s.float() * 2.0).reshape(1).contiguous()
+        gt = torch.empty_like(t)
+        gin = g_t.contiguous() if g_t is not None else None
+        H.pair_grad(t[:n], t[n:], w, coef, gin[:n] if gin is not None else None, gin[n:] if gin is not None else None,
+                    gt[:n], gt[n:])
+        return gt, None
+
+
+def halves_sq_tap(t, w):
+    """``t`` (to be used in place of the argument from here on) and the pair term of its two batch halves."""
+    return _HalvesTapFn.apply(t, w)
+
+
 def l1_sum(a, b):
     return _PairReduceFn.apply(a, b, None, H.RED_L1)
 

@@ -822,3 +822,39 @@ def test_reflect_fold_in_the_conv_epilogue_matches_the_fold_pass(case):
     a, b = got[:, ~single].float(), want[:, ~single].float()
     assert float((a - b).abs().max()) <= 2.0 ** -6 * float(b.abs().max())
     assert float((a - b).norm() / b.norm()) < 4e-3
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32], ids=["bf16", "fp32"])
+def test_path_loss_tap_matches_the_two_consumer_form(dt):
+    """ops.halves_sq_tap (o2m_pair_grad): a feature map taken THROUGH the path-loss pair term on its way to the next
+    layer gets, in one backward pass, the gradient that autograd forms from the separate term (halves_sq_sum: reduce_bwd
+    + negation) plus the next layer's gradient (accumulation add).  Same value of the term, same gradient to bf16
+    rounding (the fused form rounds once instead of three times)."""
+    from one_to_many_gan_amd import ops
+
+    torch.manual_seed(11)
+    dev = "cuda"
+    t0 = torch.randn(8, 12, 20, 64, device=dev).to(dt)
+    k = torch.randn(8, 12, 20, 64, device=dev).to(dt)   # stands for the next layer: its gradient is k
+    w = torch.rand(4, device=dev) + 0.5
+    a = t0.clone().requires_grad_(True)
+    term_a = ops.halves_sq_sum(a, w)
+    (0.37 * term_a + (a.float() * k.float()).sum()).backward()
+    b = t0.clone().requires_grad_(True)
+    tb, term_b = ops.halves_sq_tap(b, w)
+    (0.37 * term_b + (tb.float() * k.float()).sum()).backward()
+    assert torch.equal(term_a, term_b)
+    ref = k.double() + 0.37 * 2 * torch.cat([(t0[:4].double() - t0[4:].double()) * w.double().view(4, 1, 1, 1),
+                                            -(t0[:4].double() - t0[4:].double()) * w.double().view(4, 1, 1, 1)], 0)
+    tol = 1e-2 if dt == torch.bfloat16 else 1e-5
+    assert float((b.grad.double() - ref).abs().max()) <= tol * float(ref.abs().max())
+    assert float((a.grad.double() - ref).abs().max()) <= 3 * tol * float(ref.abs().max())
+    # the term alone (no other consumer of the map) and the map alone (term unused)
+    c = t0.clone().requires_grad_(True)
+    _, term_c = ops.halves_sq_tap(c, w)
+    term_c.backward()
+    assert float((c.grad.double() - (ref - k.double()) / 0.37).abs().max()) <= tol * float(ref.abs().max())
+    e = t0.clone().requires_grad_(True)
+    te, _ = ops.halves_sq_tap(e, w)
+    (te.float() * k.float()).sum().backward()
+    assert torch.equal(e.grad, k)
