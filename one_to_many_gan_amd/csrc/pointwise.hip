@@ -508,11 +508,8 @@ template <> struct RawVec<float> {
 // conv -> InstanceNorm -> (Leaky)ReLU -> DownSample chains of the encoder and of the discriminator / style extractor
 // (builder.py:170-173,272-282) without the normalised map ever being written: it is not needed by the backward
 // pass either (InstanceNorm differentiates through x and the statistics, the activation mask is the sign of xh).
-#ifndef O2M_RS_WAVES
-#define O2M_RS_WAVES 3  // waves per SIMD the register allocation must leave room for (A/B: tools/build_variant.sh)
-#endif
 template <typename T, int TY, int TX, int SY, int SX, bool NORM = false>
-__global__ __launch_bounds__(NT, O2M_RS_WAVES) void resample2x2_kernel(const T* __restrict__ x, T* __restrict__ y,
+__global__ __launch_bounds__(NT) void resample2x2_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                          const int* __restrict__ sy,
                                                          const float* __restrict__ wy,
                                                          const int* __restrict__ sx,
@@ -559,68 +556,30 @@ __global__ __launch_bounds__(NT, O2M_RS_WAVES) void resample2x2_kernel(const T* 
     for (int c = 0; c < 2; ++c)
 #pragma unroll
       for (int i = 0; i < 8; ++i) acc[a][c][i] = 0.f;
-  if constexpr (!NORM) {
 #pragma unroll
-    for (int r = 0; r < PY; ++r) {
-      const int iy = min(y0 + r, H - 1);
-      float h0[8], h1[8];
+  for (int r = 0; r < PY; ++r) {
+    const int iy = min(y0 + r, H - 1);
+    float h0[8], h1[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) h0[i] = h1[i] = 0.f;
+    for (int i = 0; i < 8; ++i) h0[i] = h1[i] = 0.f;
 #pragma unroll
-      for (int k = 0; k < PX; ++k) {
-        const int ix = min(x0 + k, W - 1);
-        float v[8];
-        load8(base + ((size_t)iy * W + ix) * C, v);
+    for (int k = 0; k < PX; ++k) {
+      const int ix = min(x0 + k, W - 1);
+      float v[8];
+      load8(base + ((size_t)iy * W + ix) * C, v);
+      if constexpr (NORM) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { h0[i] += cx[0][k] * v[i]; h1[i] += cx[1][k] * v[i]; }
+        for (int i = 0; i < 8; ++i) v[i] = act_fwd_piecewise((v[i] - mu[i]) * rs[i], relu, neg);
       }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        acc[0][0][i] += cy[0][r] * h0[i];
-        acc[0][1][i] += cy[0][r] * h1[i];
-        acc[1][0][i] += cy[1][r] * h0[i];
-        acc[1][1][i] += cy[1][r] * h1[i];
-      }
+      for (int i = 0; i < 8; ++i) { h0[i] += cx[0][k] * v[i]; h1[i] += cx[1][k] * v[i]; }
     }
-  } else {
-    // The patch rows are fetched in groups of RG rows, all loads of a group issued before its first use: a row's
-    // arithmetic is ~0.5 us, an HBM round trip ~2 us, and with the loads issued row by row a wave paid that latency
-    // PY times over (this form ran at 2.1 TB/s; 132 VGPRs = 3 waves per SIMD do not hide it).  The empty asm between
-    // groups keeps the compiler from hoisting every load of the patch to the top (258 VGPRs, one wave per SIMD).
-    constexpr int RG = PY % 3 == 0 ? 3 : (PY % 2 == 0 ? 2 : 1);
 #pragma unroll
-    for (int r0 = 0; r0 < PY; r0 += RG) {
-      RawVec<T> raw[RG][PX];
-#pragma unroll
-      for (int rr = 0; rr < RG; ++rr) {
-        const int iy = min(y0 + r0 + rr, H - 1);
-#pragma unroll
-        for (int k = 0; k < PX; ++k) raw[rr][k].load(base + ((size_t)iy * W + min(x0 + k, W - 1)) * C);
-      }
-#pragma unroll
-      for (int rr = 0; rr < RG; ++rr) {
-        const int r = r0 + rr;
-        float h0[8], h1[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) h0[i] = h1[i] = 0.f;
-#pragma unroll
-        for (int k = 0; k < PX; ++k) {
-          float v[8];
-          raw[rr][k].unpack(v);
-#pragma unroll
-          for (int i = 0; i < 8; ++i) v[i] = act_fwd_piecewise((v[i] - mu[i]) * rs[i], relu, neg);
-#pragma unroll
-          for (int i = 0; i < 8; ++i) { h0[i] += cx[0][k] * v[i]; h1[i] += cx[1][k] * v[i]; }
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          acc[0][0][i] += cy[0][r] * h0[i];
-          acc[0][1][i] += cy[0][r] * h1[i];
-          acc[1][0][i] += cy[1][r] * h0[i];
-          acc[1][1][i] += cy[1][r] * h1[i];
-        }
-      }
-      asm volatile("" ::: "memory");
+    for (int i = 0; i < 8; ++i) {
+      acc[0][0][i] += cy[0][r] * h0[i];
+      acc[0][1][i] += cy[0][r] * h1[i];
+      acc[1][0][i] += cy[1][r] * h0[i];
+      acc[1][1][i] += cy[1][r] * h1[i];
     }
   }
   T* o00 = y + (((size_t)b * Ho + oy0) * Wo + ox0) * C + cv * 8;
@@ -642,11 +601,15 @@ __global__ __launch_bounds__(NT, O2M_RS_WAVES) void resample2x2_kernel(const T* 
 // two 1-D passes this replaces moved the intermediate map through HBM and ran their row walk at ~2 TB/s.
 // The vertical weights are block-uniform: re-indexed on the patch rows (zero outside an output's band) they
 // sit in SGPRs and the row walk has only static register indices.
-template <typename T, int TY, int TX, int SY, int SX, int OH, int OW>
+// NORM: the operator is applied to act(InstanceNorm(x)) formed as the rows are unpacked (as resample2x2_kernel's NORM
+// form, whose per-thread 6 x 6 patch walk ran at 2.1 TB/s: 260 VGPRs -- one wave per SIMD -- and every patch element
+// normalised 2.25 times; here each element is fetched and normalised once per tile, all rows of a column in flight).
+template <typename T, int TY, int TX, int SY, int SX, int OH, int OW, bool NORM = false>
 __global__ __launch_bounds__(NT) void resample_tile_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                            const int* __restrict__ sy, const float* __restrict__ wy,
                                                            const int* __restrict__ sx, const float* __restrict__ wx,
-                                                           int H, int W, int Ho, int Wo, int C, int CVB, int tiles_x) {
+                                                           int H, int W, int Ho, int Wo, int C, int CVB, int tiles_x,
+                                                           const float* __restrict__ mean_rstd = nullptr, int act = 0) {
   constexpr int PH = SY * (OH - 1) + TY, PW = SX * (OW - 1) + TX;
   extern __shared__ float sm[];  // [OH][PW][2][CVB][4]
   const int chunk = blockIdx.x / tiles_x, tx_ = blockIdx.x - chunk * tiles_x;
@@ -666,6 +629,17 @@ __global__ __launch_bounds__(NT) void resample_tile_kernel(const T* __restrict__
     const int pc = item / CVB, cv = item - pc * CVB;
     const int ix = min(x_start + pc, W - 1);
     const T* col = base + (size_t)ix * C + cv * 8;
+    float mu[NORM ? 8 : 1], rs[NORM ? 8 : 1];
+    const bool relu = act == O2M_ACT_RELU;
+    const float neg = act == O2M_ACT_LRELU ? 0.2f : 1.f;
+    if constexpr (NORM) {
+      const float* mr = mean_rstd + ((size_t)b * C + (size_t)chunk * CVB * 8 + cv * 8) * 2;
+#pragma unroll
+      for (int i = 0; i < 8; i += 2) {
+        const f32x4 m4 = *reinterpret_cast<const f32x4*>(mr + 2 * i);
+        mu[i] = m4[0]; rs[i] = m4[1]; mu[i + 1] = m4[2]; rs[i + 1] = m4[3];
+      }
+    }
     if (regular) {
       RawVec<T> raw[PH];  // all PH row loads in flight as raw 16-B (32-B) vectors, unpacked one row at a time
 #pragma unroll
@@ -679,6 +653,10 @@ __global__ __launch_bounds__(NT) void resample_tile_kernel(const T* __restrict__
       for (int r = 0; r < PH; ++r) {
         float v[8];
         raw[r].unpack(v);
+        if constexpr (NORM) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] = act_fwd_piecewise((v[i] - mu[i]) * rs[i], relu, neg);
+        }
 #pragma unroll
         for (int o = 0; o < OH; ++o) {
           const int t = r - SY * o;  // compile-time
@@ -708,6 +686,10 @@ __global__ __launch_bounds__(NT) void resample_tile_kernel(const T* __restrict__
         for (int t = 0; t < TY; ++t) {
           float v[8];
           load8(col + (size_t)min(y0r + t, H - 1) * W * C, v);
+          if constexpr (NORM) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = act_fwd_piecewise((v[i] - mu[i]) * rs[i], relu, neg);
+          }
           const float w = wy[oy * TY + t];
 #pragma unroll
           for (int i = 0; i < 8; ++i) acc[i] += w * v[i];
@@ -1349,6 +1331,23 @@ int o2m_instnorm_act_resample2d(const void* x, const float* mean_rstd, void* y, 
   if (T_ != 4 || span_y < 2 || span_y > 3 || span_x < 2 || span_x > 3 || B > 65535 || (Ho + 1) / 2 > 65535)
     return O2M_ERR_UNSUPPORTED;  // the DownSample operators (4 taps, starts 2 or 3 apart); the caller falls back
   hipStream_t s = static_cast<hipStream_t>(stream);
+  // even maps (every start exactly two apart): the tile form -- 8 x 7 outputs of 16 channel vectors per block, a
+  // 18 x 16 patch whose 256 (column, vector) items are one per thread
+  static const int tile_on = [] { const char* e = getenv("O2M_NORM_DOWN_TILE"); return e ? atoi(e) : 1; }();
+  if (tile_on && span_y == 2 && span_x == 2 && (C / 8) % 16 == 0 && (Ho + 7) / 8 <= 65535) {
+    constexpr int OH = 8, OW = 7, PW = 2 * (OW - 1) + 4, CVB = 16;
+    const int tiles_x = (Wo + OW - 1) / OW, tiles_y = (Ho + OH - 1) / OH;
+    const size_t lds = (size_t)OH * PW * 2 * CVB * 16;
+    const dim3 tgrid((unsigned)(tiles_x * (C / 8 / CVB)), (unsigned)tiles_y, (unsigned)B);
+    DISPATCH_T(dtype, {
+      auto kern = resample_tile_kernel<T, 4, 4, 2, 2, OH, OW, true>;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(kern, tgrid, dim3(NT), lds, s, (const T*)x, (T*)y, sy, wy, sx, wx, H, W, Ho, Wo, C, CVB, tiles_x,
+                         mean_rstd, act);
+    });
+    O2M_LAUNCH_CHECK();
+    return 0;
+  }
   const dim3 grid((unsigned)((((long)(Wo + 1) / 2) * (C / 8) + NT - 1) / NT), (unsigned)((Ho + 1) / 2), (unsigned)B);
 #define O2M_IN_DOWN(SY, SX)                                                                                      \
   if (span_y == SY && span_x == SX) {                                                                            \

@@ -758,7 +758,10 @@ def test_fused_instance_norm_activation_downsample_matches_the_two_passes(dt):
     pk.set_precision("fp32" if dt == torch.float32 else "bf16")
     try:
         torch.manual_seed(31)
-        for (B, Hh, Ww, C, act) in ((2, 64, 64, 32, H.ACT_RELU), (3, 126, 126, 16, H.ACT_LRELU), (2, 62, 30, 64, H.ACT_LRELU)):
+        # (C = 128 / 256 on even maps: the tile form of the forward -- 8 x 7 output tiles, so 36 x 20 and 64 x 64 outputs
+        #  cover partial tiles in both directions and the clamped first / last tile rows)
+        for (B, Hh, Ww, C, act) in ((2, 64, 64, 32, H.ACT_RELU), (3, 126, 126, 16, H.ACT_LRELU), (2, 62, 30, 64, H.ACT_LRELU),
+                                    (2, 72, 40, 128, H.ACT_RELU), (2, 128, 128, 256, H.ACT_LRELU)):
             x = (torch.randn(B, Hh, Ww, C, device="cuda") * 2 + 0.3).to(dt)
             ws = torch.empty(H.instnorm_ws_floats(B, Hh * Ww, C), device="cuda")
             mr = torch.empty(B, C, 2, device="cuda")
