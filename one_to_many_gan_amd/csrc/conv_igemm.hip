@@ -180,7 +180,10 @@ struct FoldMap {
 
 // WIDE: Ci % 64 == 0, so one 64-element stage lies inside ONE filter tap (tap-outer walk).
 // !WIDE: small Ci (image stems, Ci = 8..32): every 16-B chunk decodes its own tap.
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool IN_SCALE, bool WIDE>
+// FOLD: o2m_conv_desc.fold_pad handled by the epilogue.  A separate instantiation (only the 128 x 128 tile, which takes
+// the p8 kernel's tail rows and the layers p8 does not cover): compiled into every tile it cost 14-19 VGPRs -- the
+// 256 x 64 / 128 x 64 / 256 x 32 tiles went from 120 to 134-139, i.e. from two blocks per CU to one (2.9 -> 4.1 ms per step).
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, bool IN_SCALE, bool WIDE, bool FOLD = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(const o2m_conv_desc d, const int m_begin,
                                                                                 const int m_end) {
   constexpr int NT = 64 * WAVES_M * WAVES_N;
@@ -570,7 +573,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
   const int wpp = d.stats ? 1 : WPP_MAX;  // wave rows per pass
   const int npass = WAVES_M / wpp;
   const int wrow_ = wave / WAVES_N;
-  const int foldp = d.fold_pad;
+  const int foldp = FOLD ? d.fold_pad : 0;
   const FoldMap fmap(foldp, Ho, Wo, M);
 #pragma unroll 1
   for (int pass = 0; pass < npass; ++pass) {
@@ -599,7 +602,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
       const f32x4 b = *reinterpret_cast<const f32x4*>(csm + row * CSTR + ec8 * 8 + 4);
       float o[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
       bool f_interior = true, f_atomic = false;
-      const size_t off = foldp ? (size_t)fmap.pixel(m, f_interior, f_atomic) * Co + en : (size_t)m * Co + en;
+      size_t off = (size_t)m * Co + en;
+      if constexpr (FOLD) off = (size_t)fmap.pixel(m, f_interior, f_atomic) * Co + en;
       float xv[8];
       if (dot_mode) {  // style dot of the data gradient: sum over pixels of (unscaled result) * aux
         load8x(AUX + off, xv, stream_out);
@@ -631,13 +635,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
         for (int q = 0; q < 8; ++q) { st[q] += o[q]; st[8 + q] += o[q] * o[q]; }
       }
       act_fwd8(o, act);
-      if (R && f_interior) {
+      if (R && (!FOLD || f_interior)) {
         float rv[8];
         load8(R + off, rv);
 #pragma unroll
         for (int q = 0; q < 8; ++q) o[q] += rv[q];
       }
-      if (f_atomic) atomic_add8(Y + off, o);
+      if (FOLD && f_atomic) atomic_add8(Y + off, o);
       else if (stream_out) store8_stream(Y + off, o);
       else store8(Y + off, o);
     }
@@ -1369,7 +1373,14 @@ int launch_cfg(const o2m_conv_desc& d, hipStream_t s, long m_begin = 0, long m_e
   const bool wide = d.Ci % BK == 0;
   LaunchScope timed(s, 2.0 * (m_end - m_begin) * d.Co * d.KH * d.KW * d.Ci, "conv_igemm<%s,%dx%d,in_scale=%d>",
                     sizeof(T) == 2 ? "bf16" : "f32x3", BM, BN, d.in_scale ? 1 : 0);
-  if (d.in_scale) {
+  if (d.fold_pad) {  // (validated: bf16, no in_scale; launch_dtype routes every fold launch to the 128 x 128 tile)
+    if constexpr (sizeof(T) == 2 && BM == 128 && BN == 128) {
+      if (wide) go(conv_igemm_kernel<T, BM, BN, WAVES_M, WAVES_N, false, true, true>);
+      else go(conv_igemm_kernel<T, BM, BN, WAVES_M, WAVES_N, false, false, true>);
+    } else {
+      return O2M_ERR_UNSUPPORTED;
+    }
+  } else if (d.in_scale) {
     if (wide) go(conv_igemm_kernel<T, BM, BN, WAVES_M, WAVES_N, true, true>);
     else go(conv_igemm_kernel<T, BM, BN, WAVES_M, WAVES_N, true, false>);
   } else {
@@ -1411,9 +1422,11 @@ int launch_dtype(const o2m_conv_desc& d, hipStream_t s) {
         return launch_p8(d, s, 0, rows);
       }
     }
+    if (d.fold_pad) return launch_cfg<T, 128, 128, 2, 2>(d, s);
     if (tiles_for<256, 256>(d) >= kFillBlocks) return launch_cfg<T, 256, 256, 2, 4>(d, s);
     return launch_cfg<T, 128, 128, 2, 2>(d, s);
   }
+  if (d.fold_pad) return launch_cfg<T, 128, 128, 2, 2>(d, s);  // (the one tile compiled with the fold epilogue)
   if (d.Co > 64) {
     // short reductions (<= 18 stages) are dominated by per-block prologue / epilogue: 256x64 tiles
     // need 80 KB of LDS and ~110 VGPRs, so TWO blocks share a CU and overlap each other
@@ -1521,7 +1534,8 @@ extern "C" int o2m_conv2d_fwd(const o2m_conv_desc* d, void* stream) {
   if (d->fold_pad < 0 || d->reserved1 != 0) return O2M_ERR_BAD_ARG;
   if (d->fold_pad > 0) {  // data gradient of a reflection-padded conv, folded in the epilogue (header)
     const int f = d->fold_pad, Ho = d->H + 2 * d->pad - d->KH + 1, Wo = d->W + 2 * d->pad - d->KW + 1;
-    if (d->dtype != O2M_BF16 || d->act != O2M_ACT_NONE || d->stats || d->aux || d->stride > 1 || d->w_batch_stride > 0)
+    if (d->dtype != O2M_BF16 || d->act != O2M_ACT_NONE || d->stats || d->aux || d->stride > 1 || d->w_batch_stride > 0 ||
+        d->in_scale)
       return O2M_ERR_BAD_ARG;
     if (Ho - 2 * f < 2 * f + 2 || Wo - 2 * f < 2 * f + 2) return O2M_ERR_BAD_ARG;
     if ((long)d->B * x_sample > 0x7fffffffL) return O2M_ERR_UNSUPPORTED;  // (no batch slicing in this form)

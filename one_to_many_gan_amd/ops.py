@@ -810,12 +810,14 @@ class _ConvFn(torch.autograd.Function):
                              stats=part, aux=x, aux_scaled=xs)
                 dots = torch.empty((B, cip), dtype=torch.float32, device=dev)
                 H.conv2d_dots_finalize(part, dots, nchunks)
-            elif (_FOLD_EPILOGUE and s is None and pad_mode == H.PAD_REFLECT and g.dtype == torch.bfloat16
+            elif (_FOLD_EPILOGUE and s is None and pad_mode == H.PAD_REFLECT and pad == 1 and g.dtype == torch.bfloat16
                   and not deterministic() and not prep.fp8_ok(True, B * hp * wp)
                   and min(Hh, Ww) >= 2 * pad + 2):
-                # plain conv behind ReflectionPad2d (the encoder's residual blocks, the image stem / head): the GEMM's
-                # epilogue adds every pixel of the padded domain at its mirror image of g_x (o2m_conv_desc.fold_pad)
-                # and the block's residual gradient with it -- no padded gradient, no fold pass
+                # plain 3 x 3 conv behind ReflectionPad2d(1) (the encoder's residual blocks): the GEMM's epilogue adds
+                # every pixel of the padded domain at its mirror image of g_x (o2m_conv_desc.fold_pad) and the block's
+                # residual gradient with it -- no padded gradient, no fold pass.  (Not the 7 x 7 head behind
+                # ReflectionPad2d(3): 9 % of its 256 x 256 x 64 map would go through atomics -- 14 M of them per launch of
+                # a 0.4 ms kernel, measured +1.3 ms -- profiles/README.md.)
                 g_x = torch.empty_like(x)
                 H.conv2d_fwd(gu, w_d, g_x, pad=kpad, pad_mode=H.PAD_ZERO, act=H.ACT_NONE, residual=res_in, fold_pad=pad)
                 res_in = None
