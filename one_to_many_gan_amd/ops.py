@@ -1148,25 +1148,74 @@ def _apply_taps(x, taps):
     return y
 
 
-class _ResampleFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, kind):
-        B, Hh, Ww, Cn = x.shape
-        y = _apply_taps(x, R.taps(kind, Hh, Ww, False, x.device))
-        ctx.kind, ctx.hw = kind, (Hh, Ww)
-        return y
+# ---- functional operators registered with the dispatcher ------------------------------------------------------------
+# the reference's operator API is torch.nn.functional; the build's is namespace o2m::.  The
+# launchers are out-variant ops (csrc/torch_ops.cpp: TORCH_LIBRARY(o2m, ...)); the FUNCTIONAL forms below -- the ones with a
+# derivative and no Python-side state -- are defined as fragment ops of the same namespace with their autograd formula
+# attached by torch.library.register_autograd, so torch.ops.o2m.resample / pair_sum / moments / instance_norm_act
+# differentiate like any ATen op (and carry a fake kernel for shape inference).  The conv functions keep a
+# torch.autograd.Function: their backward hands tensors between the two convs of a block (BlockLink), defers work to
+# other streams and accumulates weight gradients in kernel layout across uses -- state an operator schema cannot carry.
+_RESAMPLE_KINDS = ("blur", "up", "down")
 
-    @staticmethod
-    def backward(ctx, g):
-        g = g.contiguous()
-        Hh, Ww = ctx.hw
-        gx = _apply_taps(g, R.taps(ctx.kind, Hh, Ww, True, g.device))
-        return gx, None
+
+def _resample_out_hw(kind, Hh, Ww, transposed):
+    if kind == "blur":
+        return Hh, Ww
+    if (kind == "up") != transposed:
+        return 2 * Hh, 2 * Ww
+    return Hh // 2, Ww // 2
+
+
+@torch.library.custom_op("o2m::resample", mutates_args=())
+def _resample_op(x: torch.Tensor, kind: str) -> torch.Tensor:
+    B, Hh, Ww, Cn = x.shape
+    return _apply_taps(x.contiguous(), R.taps(kind, Hh, Ww, False, x.device))
+
+
+@_resample_op.register_fake
+def _(x, kind):
+    ho, wo = _resample_out_hw(kind, x.shape[1], x.shape[2], False)
+    return x.new_empty((x.shape[0], ho, wo, x.shape[3]))
+
+
+@torch.library.custom_op("o2m::resample_transposed", mutates_args=())
+def _resample_t_op(g: torch.Tensor, kind: str, height: int, width: int) -> torch.Tensor:
+    """Adjoint of o2m::resample on an input of height x width."""
+    return _apply_taps(g.contiguous(), R.taps(kind, height, width, True, g.device))
+
+
+@_resample_t_op.register_fake
+def _(g, kind, height, width):
+    return g.new_empty((g.shape[0], height, width, g.shape[3]))
+
+
+def _resample_setup(ctx, inputs, output):
+    x, kind = inputs
+    ctx.kind, ctx.hw = kind, (x.shape[1], x.shape[2])
+
+
+def _resample_bwd(ctx, g):
+    return torch.ops.o2m.resample_transposed(g, ctx.kind, ctx.hw[0], ctx.hw[1]), None
+
+
+def _resample_t_setup(ctx, inputs, output):
+    ctx.kind = inputs[1]
+
+
+def _resample_t_bwd(ctx, gg):  # the adjoint of the adjoint is the operator
+    return torch.ops.o2m.resample(gg, ctx.kind), None, None, None
+
+
+torch.library.register_autograd("o2m::resample", _resample_bwd, setup_context=_resample_setup)
+torch.library.register_autograd("o2m::resample_transposed", _resample_t_bwd, setup_context=_resample_t_setup)
 
 
 def resample(x, kind):
     """kind in {"blur", "up", "down"} (Smooth / UpSample / DownSample of layers.py)."""
-    return _ResampleFn.apply(x, kind)
+    if kind not in _RESAMPLE_KINDS:
+        raise ValueError(kind)
+    return torch.ops.o2m.resample(x, kind)
 
 
 # ---------------------------------------------------------------------------------- losses
@@ -1176,45 +1225,76 @@ def _partials(n_elems, n_out, device):
     return torch.empty(n_out * H.reduce_blocks(n_elems), dtype=torch.float32, device=device)
 
 
-class _PairReduceFn(torch.autograd.Function):
-    """sum over all elements of |a-b| (L1) or w[b]*(a-b)^2 (SQ); returns an fp32 scalar."""
-
-    @staticmethod
-    def forward(ctx, a, b, w, mode):
-        part = _partials(a.numel(), 1, a.device)
-        H.reduce_fwd(a, b, w, part, mode)
-        ctx.mode = mode
-        ctx.save_for_backward(a, b, w)
-        return part.sum()
-
-    @staticmethod
-    def backward(ctx, g):
-        a, b, w = ctx.saved_tensors
-        coef = (g.float() * (2.0 if ctx.mode == H.RED_SQ else 1.0)).reshape(1).contiguous()
-        ga = torch.empty_like(a)
-        H.reduce_bwd(a, b, w, coef, ga, ctx.mode)
-        gb = -ga if (b is not None and ctx.needs_input_grad[1]) else None
-        return (ga if ctx.needs_input_grad[0] else None), gb, None, None
+@torch.library.custom_op("o2m::pair_sum", mutates_args=())
+def _pair_sum_op(a: torch.Tensor, b: torch.Tensor | None, w: torch.Tensor | None, mode: int) -> torch.Tensor:
+    """sum over all elements of |a-b| (mode RED_L1) or w[b]*(a-b)^2 (RED_SQ); an fp32 scalar."""
+    part = _partials(a.numel(), 1, a.device)
+    H.reduce_fwd(a, b, w, part, mode)
+    return part.sum()
 
 
-class _MomentsFn(torch.autograd.Function):
+@_pair_sum_op.register_fake
+def _(a, b, w, mode):
+    return a.new_empty((), dtype=torch.float32)
+
+
+@torch.library.custom_op("o2m::pair_sum_grad", mutates_args=())
+def _pair_sum_grad_op(a: torch.Tensor, b: torch.Tensor | None, w: torch.Tensor | None, coef: torch.Tensor,
+                      mode: int) -> torch.Tensor:
+    """d pair_sum / d a scaled by the device scalar coef (the gradient of b is its negative)."""
+    ga = torch.empty_like(a)
+    H.reduce_bwd(a, b, w, coef, ga, mode)
+    return ga
+
+
+@_pair_sum_grad_op.register_fake
+def _(a, b, w, coef, mode):
+    return torch.empty_like(a)
+
+
+def _pair_sum_setup(ctx, inputs, output):
+    a, b, w, mode = inputs
+    ctx.mode = mode
+    ctx.save_for_backward(a, b, w)
+
+
+def _pair_sum_bwd(ctx, g):
+    a, b, w = ctx.saved_tensors
+    coef = (g.float() * (2.0 if ctx.mode == H.RED_SQ else 1.0)).reshape(1).contiguous()
+    ga = torch.ops.o2m.pair_sum_grad(a, b, w, coef, ctx.mode)
+    gb = -ga if (b is not None and ctx.needs_input_grad[1]) else None
+    return (ga if ctx.needs_input_grad[0] else None), gb, None, None
+
+
+torch.library.register_autograd("o2m::pair_sum", _pair_sum_bwd, setup_context=_pair_sum_setup)
+
+
+@torch.library.custom_op("o2m::moments", mutates_args=())
+def _moments_op(a: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
     """(sum a, sum a^2) as fp32 scalars (kl_loss_func, loss.py:86-87)."""
+    nb = H.reduce_blocks(a.numel())
+    part = _partials(a.numel(), 2, a.device)
+    H.reduce_fwd(a, None, None, part, H.RED_MOM)
+    return part[:nb].sum(), part[nb:].sum()
 
-    @staticmethod
-    def forward(ctx, a):
-        nb = H.reduce_blocks(a.numel())
-        part = _partials(a.numel(), 2, a.device)
-        H.reduce_fwd(a, None, None, part, H.RED_MOM)
-        ctx.save_for_backward(a)
-        return part[:nb].sum(), part[nb:].sum()
 
-    @staticmethod
-    def backward(ctx, g1, g2):
-        (a,) = ctx.saved_tensors
-        coef = torch.stack([g1.float(), 2.0 * g2.float()]).contiguous()
-        ga = torch.empty_like(a)
-        H.reduce_bwd(a, None, None, coef, ga, H.RED_MOM)
-        return ga
+@_moments_op.register_fake
+def _(a):
+    return a.new_empty((), dtype=torch.float32), a.new_empty((), dtype=torch.float32)
+
+
+def _moments_setup(ctx, inputs, output):
+    ctx.save_for_backward(inputs[0])
+
+
+def _moments_bwd(ctx, g1, g2):
+    (a,) = ctx.saved_tensors
+    z = torch.zeros((), dtype=torch.float32, device=a.device)
+    coef = torch.stack([(g1 if g1 is not None else z).float(), 2.0 * (g2 if g2 is not None else z).float()]).contiguous()
+    return torch.ops.o2m.pair_sum_grad(a, None, None, coef, H.RED_MOM)
+
+
+torch.library.register_autograd("o2m::moments", _moments_bwd, setup_context=_moments_setup)
 
 
 class _HalvesSqFn(torch.autograd.Function):
@@ -1280,12 +1360,12 @@ def halves_sq_tap(t, w):
 
 
 def l1_sum(a, b):
-    return _PairReduceFn.apply(a, b, None, H.RED_L1)
+    return torch.ops.o2m.pair_sum(a, b, None, H.RED_L1)
 
 
 def sq_sum(a, b=None, w=None):
-    return _PairReduceFn.apply(a, b, w, H.RED_SQ)
+    return torch.ops.o2m.pair_sum(a, b, w, H.RED_SQ)
 
 
 def moments(a):
-    return _MomentsFn.apply(a)
+    return torch.ops.o2m.moments(a)

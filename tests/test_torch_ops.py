@@ -93,3 +93,52 @@ def test_every_launch_goes_through_the_device_guard_and_train_selects_its_device
     train = open(os.path.join(root, "train.py")).read()
     run_src = train[train.index("def run("):]
     assert run_src.index("torch.cuda.set_device(device)") < run_src.index("Generator(")
+
+
+@pytest.mark.gpu
+def test_functional_ops_are_registered_with_autograd():
+    """torch.ops.o2m.resample / pair_sum / moments: functional operators of the o2m namespace whose derivative is attached
+    with torch.library.register_autograd -- they differentiate through the dispatcher like ATen
+    ops, have fake kernels (shape inference on meta tensors), pass torch.library.opcheck, and agree with the torch
+    formulas they stand for (loss.py:82-111, layers.py:191-247)."""
+    import torch.nn.functional as F
+
+    from one_to_many_gan_amd import _hip as H
+    from one_to_many_gan_amd import ops
+
+    torch.manual_seed(3)
+    dev = "cuda"
+    # ---- losses
+    a = torch.randn(4, 6, 10, 16, device=dev, requires_grad=True)
+    b = torch.randn(4, 6, 10, 16, device=dev, requires_grad=True)
+    w = torch.rand(4, device=dev) + 0.5
+    for mode, ref in ((H.RED_L1, lambda: (a - b).abs().sum()),
+                      (H.RED_SQ, lambda: (w.view(4, 1, 1, 1) * (a - b) ** 2).sum())):
+        got = torch.ops.o2m.pair_sum(a, b, w if mode == H.RED_SQ else None, mode)
+        ga, gb = torch.autograd.grad(got * 0.7, (a, b))
+        ra, rb = torch.autograd.grad(ref() * 0.7, (a, b))
+        assert abs(float(got) - float(ref())) <= 1e-4 * abs(float(ref()))
+        assert torch.allclose(ga, ra, rtol=1e-5, atol=1e-6) and torch.allclose(gb, rb, rtol=1e-5, atol=1e-6)
+    s1, s2 = torch.ops.o2m.moments(a)
+    (g,) = torch.autograd.grad(2.0 * s1 + 0.5 * s2, a)
+    assert torch.allclose(g, 2.0 + a.detach(), rtol=1e-5, atol=1e-6)
+    (g,) = torch.autograd.grad(torch.ops.o2m.moments(a)[1], a)   # one output unused
+    assert torch.allclose(g, 2.0 * a.detach(), rtol=1e-5, atol=1e-6)
+    # ---- resample: the adjoint pair (<D x, g> = <x, D^T g>) through autograd, for all three operators
+    x = torch.randn(2, 12, 20, 16, device=dev, requires_grad=True)
+    for kind in ("blur", "up", "down"):
+        y = ops.resample(x, kind)
+        gy = torch.randn_like(y)
+        (gx,) = torch.autograd.grad(y, x, gy)
+        lhs, rhs = float((y.detach().double() * gy.double()).sum()), float((x.detach().double() * gx.double()).sum())
+        assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), 1.0), kind
+        assert torch.ops.o2m.resample(torch.empty(2, 12, 20, 16, device="meta"), kind).shape == y.shape
+    ref = F.interpolate(x.detach().permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=False)
+    assert ops.resample(x, "up").shape == (2, 24, 40, 16) and ref.shape == (2, 16, 24, 40)
+    # ---- the operator checker: schema, fake kernel, autograd registration
+    torch.library.opcheck(torch.ops.o2m.pair_sum.default, (a.detach().requires_grad_(True), b.detach(), w, H.RED_SQ),
+                          test_utils=("test_schema", "test_faketensor", "test_autograd_registration"))
+    torch.library.opcheck(torch.ops.o2m.resample.default, (x.detach().requires_grad_(True), "down"),
+                          test_utils=("test_schema", "test_faketensor", "test_autograd_registration"))
+    torch.library.opcheck(torch.ops.o2m.moments.default, (a.detach().requires_grad_(True),),
+                          test_utils=("test_schema", "test_faketensor", "test_autograd_registration"))
