@@ -292,6 +292,37 @@ def cpu_baseline(size, channels, timed_steps=3, batch=2):
             "step_seconds": [round(t, 2) for t in times]}
 
 
+def graph_mode_leg(device, size=64, channels=1, batch=4, steps=20):
+    """The host-bound shape (BASELINE config #1's: 64x64x1, batch 4) eagerly and as ONE replayed HIP graph
+    (one_to_many_gan_amd/core/graphed.py: device-resident draws, history pool, controller and scalar sums).  Not the
+    headline workload: at 256x256 the replayed three-stream schedule is slower than the eager one."""
+    from one_to_many_gan_amd.core.graphed import GraphedStep
+
+    out = {"workload": f"{size}x{size}x{channels}, batch {batch}, bf16", "steps": steps}
+    for name, capture in (("eager_ms_per_step", False), ("graph_ms_per_step", True)):
+        cfg = make_config(size, channels, batch)
+        cfg["training"]["image_buffer_size"] = 4 * batch
+        tr = Trainer(product_namespace("bf16"), cfg, device)
+        gs = GraphedStep(cfg, device, {"D": tr.D, "G": tr.G, "M": tr.M, "S": tr.S},
+                         {"D": tr.oD, "G": tr.oG, "M": tr.oM, "S": tr.oS}, tr.prints, tr.marks, tr.ada, capture=capture)
+        for _ in range(10):  # pool fill, warm-up, capture
+            gs.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            gs.step()
+        torch.cuda.synchronize()
+        out[name] = round((time.perf_counter() - t0) / steps * 1e3, 3)
+        if capture:
+            out["captured"] = gs.graph is not None
+        d, g = gs.logged_means()
+        out.setdefault("finite", True)
+        out["finite"] = out["finite"] and all(v == v for v in d + g)
+        del tr, gs
+        torch.cuda.empty_cache()
+    return out
+
+
 def parity_mode_leg(args, device, steps=5, warmup=2):
     """The SAME workload in the precision that meets the 1e-3 parity gate (fp32 storage, bf16x3 split
     MFMA), timed in this run so that the gate-passing throughput is driver-measured too."""
@@ -446,6 +477,10 @@ def main():
         if (args.size, args.batch) == (256, 16) and not args.no_extra_legs:
             out["fp8_mode"] = extra_leg(args, device, "fp8", 256, 16)     # BASELINE config #5
             out["config4"] = extra_leg(args, device, "bf16", 512, 8)      # BASELINE config #4 (one GPU's share)
+            try:   # config #1's shape on the GPU: host-bound eagerly, replayed as one HIP graph (a side leg: never fatal)
+                out["graph_mode"] = graph_mode_leg(device)
+            except Exception as e:  # noqa: BLE001
+                out["graph_mode"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.size, args.channels)
     if rank == 0:

@@ -130,9 +130,15 @@ def set_async_scalars(flag: bool) -> None:
     _ASYNC_SCALARS = bool(flag) and os.environ.get("O2M_ASYNC_SCALARS", "1") != "0"  # (=0: A/B runs)
 
 
+_SCALAR_SINK = None  # core.graphed.GraphedStep: the logged scalars are summed on the device instead of returned
+
+
 def _floats(*scalars):
     """One device->host transfer for all logged scalars of a step."""
     packed = torch.stack([s.detach().float().reshape(()) for s in scalars])
+    if _SCALAR_SINK is not None:
+        _SCALAR_SINK.add(packed)
+        return [float("nan")] * len(scalars)  # (read them from the sink: ScalarSink.means_and_reset)
     if _ASYNC_SCALARS and packed.device.type == "cuda":
         pending = _PendingScalars(packed)
         return [LoggedScalar(pending, i) for i in range(len(scalars))]
@@ -221,7 +227,8 @@ def _separate_decodes(config, device, generator, discriminator, mapping_network,
     with _frozen(discriminator):
         gan = _mse_to(discriminator(ada(generated)), 1.0)
     style = style_cycle_loss_func(w_trans[-1], style_extractor(generated))
-    theta = torch.rand(batch).to(device)
+    # (device draw when the mapping network draws there too: core/graphed.py)
+    theta = torch.rand(batch, device=device) if getattr(mapping_network, "device_draws", False) else torch.rand(batch).to(device)
     lo, hi = lam["path_loss_jacobian_granularity"]
     h = torch.ones_like(theta).uniform_(lo, hi)
     d1, d2 = (theta + h / 2).clamp(0, 1), (theta - h / 2).clamp(0, 1)
@@ -247,7 +254,8 @@ def _batched_decodes(config, device, generator, discriminator, mapping_network, 
         torch.cuda.current_stream(device).wait_event(mark_ready)
         w_mark.record_stream(torch.cuda.current_stream(device))
     w_trans = mapping_network.get_single_w(batch, blocks, device, 1)
-    theta = torch.rand(batch).to(device)
+    # (device draw when the mapping network draws there too: core/graphed.py)
+    theta = torch.rand(batch, device=device) if getattr(mapping_network, "device_draws", False) else torch.rand(batch).to(device)
     lo, hi = lam["path_loss_jacobian_granularity"]
     h = torch.ones_like(theta).uniform_(lo, hi)
     d1, d2 = (theta + h / 2).clamp(0, 1), (theta - h / 2).clamp(0, 1)

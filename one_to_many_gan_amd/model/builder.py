@@ -39,6 +39,10 @@ class MappingNetwork(nn.Module):
             stack.append(nn.ReLU(inplace=True) if last else nn.LeakyReLU(0.2, inplace=True))
         self.net = nn.Sequential(*stack)
         self.register_buffer("shoeprint_style_vector", torch.zeros(1, 1, features), persistent=False)
+        # True: every draw of the style path comes from the DEVICE generator and the style mixing is a mask, not a Python
+        # branch -- the same distributions with no host dependence (a graph-capturable step: core/graphed.py).  Default:
+        # the reference's CPU draws in the reference's order.
+        self.device_draws = False
 
     def forward(self, z: torch.Tensor):
         return self.net(F.normalize(z.float(), dim=1))
@@ -47,6 +51,15 @@ class MappingNetwork(nn.Module):
         return self.forward(torch.randn(batch_size, self.d_latent).to(device))
 
     def _get_style_vector(self, batch_size, n_gen_blocks, device, *, mix_styles=True):
+        if self.device_draws:
+            # both latents always go through the MLP; blocks [0, cut) take the first, the rest the second when the step
+            # mixes (probability style_mixing_prob), all blocks the first when it does not
+            z = torch.randn(2 * batch_size, self.d_latent, device=device)
+            first, second = self.forward(z).split(batch_size, 0)
+            mix = torch.rand((), device=device) < (self.style_mixing_prob if mix_styles else -1.0)
+            cut = torch.randint(0, n_gen_blocks, (), device=device)
+            use_first = (torch.arange(n_gen_blocks, device=device) < cut) | ~mix
+            return torch.where(use_first.view(-1, 1, 1), first.unsqueeze(0), second.unsqueeze(0))
         if mix_styles and torch.rand(()).lt(self.style_mixing_prob):
             cut = int(torch.randint(0, n_gen_blocks, ()))
             # the two latents of a mixed style through the MLP as ONE 2B-row pass (same draws, in the reference's

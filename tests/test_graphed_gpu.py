@@ -1,0 +1,98 @@
+"""core/graphed.py on the GPU: the captured D+G step replays the eager step bit for bit."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(capture: bool, steps: int):
+    import bench
+    import one_to_many_gan_amd as pk
+    from one_to_many_gan_amd.core.graphed import GraphedStep
+
+    dev = torch.device("cuda:0")
+    cfg = bench.make_config(64, 1, 4)
+    cfg["training"]["image_buffer_size"] = 8      # full after two steps: capture at step 3 + warm-up
+    cfg["ada"]["ada_overfitting_measurement_n_images"] = 12   # a window of three steps: the controller closes windows
+    tr = bench.Trainer(bench.product_namespace("bf16"), cfg, dev)
+    torch.manual_seed(1234)                       # CPU and device generators: the step draws on the device only
+    gs = GraphedStep(cfg, dev, {"D": tr.D, "G": tr.G, "M": tr.M, "S": tr.S},
+                     {"D": tr.oD, "G": tr.oG, "M": tr.oM, "S": tr.oS}, tr.prints, tr.marks, tr.ada,
+                     warmup_steps=1, capture=capture)
+    means = []
+    for i in range(steps):
+        gs.step()
+        if i % 3 == 2:
+            means.append(gs.logged_means())
+    torch.cuda.synchronize()
+    state = {k: opt.bucket.flat.clone() for k, opt in gs.opts.items()}
+    state["pool"] = gs.buffer.pool.clone()
+    state["p"] = gs.ada_p.p.clone()
+    return gs, state, means
+
+
+def test_graphed_step_replays_the_eager_step_bit_for_bit():
+    """Deterministic mode, same seeds: nine D+G steps run eagerly with the device-resident draws / history pool /
+    controller / scalar sums (capture=False), and the same nine steps with the step captured after the pool has filled
+    and replayed from then on (six replays).  Every parameter of the four networks, the history pool, the controller's
+    p and the logged window means agree bit for bit -- the device generator's draws included (a replay advances the
+    generator exactly as the eager step does)."""
+    import one_to_many_gan_amd as pk
+
+    pk.set_deterministic(True)
+    try:
+        eager, a, ma = _run(False, 9)
+        graphed, b, mb = _run(True, 9)
+    finally:
+        pk.set_deterministic(False)
+    assert eager.graph is None and graphed.graph is not None
+    diff = [k for k in a if not torch.equal(a[k], b[k])]
+    assert not diff, diff
+    assert ma == mb
+    for d, g in ma:
+        assert all(v == v for v in d + g)  # finite window means of all ten scalars
+
+
+def test_train_loop_with_the_graphed_step_logs_checkpoints_and_resumes(tmp_path):
+    """train.run(graph=True): the loop around GraphedStep -- the reference's log line from the device-side window
+    means, checkpoint files in the reference's format (history pool and controller converted back to the reference
+    objects), resume from such a file -- on a 64 x 64 configuration with a pool that fills in two steps, so that
+    the last steps are graph replays."""
+    import one_to_many_gan_amd as o2m
+    import train
+    from one_to_many_gan_amd.core.evaluation import load_checkpoint
+    from one_to_many_gan_amd.core.training import ImageBuffer
+    from one_to_many_gan_amd.model.loss import ADAp
+    from tests.cases import make_config
+
+    dev = torch.device("cuda:0")
+    o2m.set_precision("bf16")
+    cfg = make_config(1, (64, 64), 2)
+    cfg["training"].update(checkpoint_directory=tmp_path, training_run="g", training_steps=8, image_buffer_size=4)
+    cfg["evaluation"] = {"log_interval": 2, "checkpoint_interval": 8, "n_evaluation_images": 0, "inference_batch_size": 2}
+    lines = []
+    nets, opts = train.run(cfg, dev, 8, train.synthetic_batches(10, cfg, dev), train.synthetic_batches(20, cfg, dev),
+                           log=lines.append, image_grids=False, graph=True)
+    torch.cuda.synchronize()
+    steps = [l for l in lines if l.startswith("Step: ")]
+    assert len(steps) == 4 and any("graph replay" in l for l in lines)
+    assert "nan" not in " ".join(steps).lower()
+    assert float(opts["G"].step_t) == 8.0 and float(opts["D"].step_t) == 8.0
+    ck = tmp_path / "g" / "models" / "8.tar"
+    assert ck.exists()
+    # the file is a reference-format checkpoint: it loads into the reference objects ...
+    ref_p, ref_buf = ADAp(1, 0.0, 1, 0.6), ImageBuffer(4)
+    first = load_checkpoint(ck, dev, nets["G"], nets["D"], nets["M"], nets["S"], ada_p=ref_p, image_buffer=ref_buf)
+    assert first == 8 and ref_buf.num_imgs == 4 and ref_buf.images[0].shape == (1, 1, 64, 64)
+    # ... and the graphed loop resumes from it
+    lines2 = []
+    _, opts2 = train.run(cfg, dev, 10, train.synthetic_batches(30, cfg, dev), train.synthetic_batches(40, cfg, dev),
+                         resume=ck, log=lines2.append, image_grids=False, graph=True)
+    torch.cuda.synchronize()
+    assert float(opts2["G"].step_t) == 10.0 and any(l.startswith("resumed from") for l in lines2)

@@ -228,3 +228,44 @@ def test_launch_timer_switch_is_host_side_state():
     assert _hip.launch_timing(True) is False
     assert _hip.launch_timing(False) is True
     assert _hip.launch_timing_read() == {}
+
+
+def test_device_resident_controller_and_history_pool_follow_the_reference_rules():
+    """core/graphed.py: DeviceADAp reproduces ADAp (loss.py:11-52, window quirk included) on a scripted score trace as
+    device arithmetic; DeviceImageBuffer keeps the reference's per-image rule (training.py:39-65): stored and returned
+    while the pool fills, afterwards every returned image is the fresh one or one that was in the pool, the pool
+    holds exactly what was put in, and about half of the images are swapped."""
+    from one_to_many_gan_amd.core.graphed import DeviceADAp, DeviceImageBuffer
+    from one_to_many_gan_amd.model.loss import ADAp
+
+    g = torch.Generator().manual_seed(4)
+    ref, dev = ADAp(20, 0.002, 4, 0.6), DeviceADAp(20, 0.002, 4, 0.6, torch.device("cpu"))
+    peak = 0.0
+    for i in range(200):
+        score = torch.rand((), generator=g) * 2 - (0.2 if (i // 40) % 2 else 1.0)
+        ref.update_p(score)
+        dev.update_p(score)
+        assert abs(ref() - dev.value()) < 1e-6, i
+        peak = max(peak, ref())
+    assert dev() == 0.0 and peak > 0  # (the trace moves p up and down; the device controller never makes the host wait)
+
+    torch.manual_seed(9)
+    buf = DeviceImageBuffer(6)
+    seen, swapped, total = set(), 0, 0
+    for step in range(40):
+        batch = torch.arange(4, dtype=torch.float32).view(4, 1, 1, 1) + 4 * step + torch.zeros(4, 1, 2, 2)
+        out = buf(batch)
+        assert out.shape == batch.shape
+        ids_in, ids_out = batch[:, 0, 0, 0].tolist(), out[:, 0, 0, 0].tolist()
+        if step == 0:
+            assert ids_out == ids_in and buf.num_imgs == 4
+        for a, b in zip(ids_in, ids_out):
+            assert b == a or b in seen, (step, a, b)   # fresh, or something stored earlier (earlier in this batch too)
+            seen.add(a)
+            if buf.full and step > 1:
+                total += 1
+                swapped += b != a
+        assert set(buf.pool[: buf.num_imgs, 0, 0, 0].tolist()) <= seen
+    assert 0.3 < swapped / total < 0.7
+    with pytest.raises(ValueError):
+        DeviceImageBuffer(0)
