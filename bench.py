@@ -267,12 +267,12 @@ def extra_leg(args, device, precision, size, batch, steps=5, warmup=2):
     return out
 
 
-def cpu_baseline(size, channels, timed_steps=3, batch=2):
+def cpu_baseline(size, channels, timed_steps=2, batch=8):
     """The CPU oracle (a restatement of the reference's own CPU path, pinned against it) timed the
     way SURVEY.md section 8d prescribes -- all host cores of the GPU's share, 1 warm-up step, then
-    >= 3 timed D+G steps -- on a BOUNDED sample: batch 2 instead of 16.  A B = 16 step costs ~95 s
-    on 16 cores, so warm-up + 3 steps would take > 6 minutes; at B = 2 the whole leg is ~45 s, and
-    images/sec of this conv-bound step is flat in B on the CPU (each sample is its own GEMM row block)."""
+    timed D+G steps -- on a BOUNDED sample: batch 8 instead of 16, 2 timed steps (a B = 16 step
+    costs ~95 s on 16 cores, so warm-up + 3 steps would take > 6 minutes; at B = 8 the leg is ~2.5 minutes and the
+    default bench.py run still finishes in about four)."""
     cores = min(len(os.sched_getaffinity(0)), 16)  # the GPU box gives one GPU a 16-core share
     torch.set_num_threads(cores)
     tr = Trainer(oracle_namespace(), make_config(size, channels, batch), torch.device("cpu"))
@@ -287,7 +287,7 @@ def cpu_baseline(size, channels, timed_steps=3, batch=2):
     dt = sum(times) / len(times)
     return {"value": round(batch / dt, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"1 warm-up + {timed_steps} timed D+G steps at batch {batch} (bounded sample of the batch-16 "
-                      f"workload: a batch-16 step is ~95 s of CPU), {size}x{size}x{channels}, fp32, CPU oracle",
+                      f"workload: half its batch; a batch-16 step is ~95 s of CPU), {size}x{size}x{channels}, fp32, CPU oracle",
             "seconds_per_step": round(dt, 2), "warmup_seconds": round(warm, 2),
             "step_seconds": [round(t, 2) for t in times]}
 

@@ -74,6 +74,14 @@ typedef struct o2m_launch_stat {
 int32_t o2m_launch_timing(int32_t enable);
 int32_t o2m_launch_timing_read(o2m_launch_stat* out, int32_t capacity);
 
+/* Test hook (tests/test_hip_parity.py; never called by the product path): the number of workgroups the tile
+ * selection of o2m_conv2d_fwd treats as "one per CU" (default 256: the phase-pipelined 256 x 256 kernel needs that
+ * many tiles, the halo kernel twice as many, ...).  With a small value the parity cases the CPU oracle finishes in
+ * seconds (gen64_deep, steps128: a handful of tiles) are ROUTED to the kernels the full-size step selects, so those
+ * kernels -- not the generic tiles -- are what the oracle and the reference fixtures check.  n <= 0 restores the
+ * default; returns the previous value.  No reference counterpart (the reference has no tile selection). */
+int32_t o2m_debug_fill_blocks(int32_t n);
+
 /* ------------------------------------------------------------------------------------
  * Implicit-GEMM convolution on MFMA (v_mfma_f32_32x32x16_bf16), stride 1, dilation 1.
  *   y[b,oy,ox,o] = act( out_scale[b,o] * sum_{kh,kw,i} w[o,kh,kw,i] *

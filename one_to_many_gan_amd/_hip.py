@@ -33,7 +33,7 @@ ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 PAD_ZERO, PAD_REFLECT = 0, 1
 RED_L1, RED_SQ, RED_MOM = 0, 1, 2
 STATS_MOMENTS, STATS_DOT = 0, 1
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -68,6 +68,7 @@ SIGNATURES = {
     "o2m_abi_version": (_i32, []),
     "o2m_launch_timing": (_i32, [_i32]),
     "o2m_launch_timing_read": (_i32, [_vp, _i32]),
+    "o2m_debug_fill_blocks": (_i32, [_i32]),
     "o2m_conv2d_fwd": (_i32, [C.POINTER(ConvDesc), _vp]),
     "o2m_conv2d_stats_rows": (_i32, [C.POINTER(ConvDesc)]),
     "o2m_conv2d_dots_finalize": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp]),
@@ -110,7 +111,7 @@ SIGNATURES = {
 }
 
 _lib = None
-MEASUREMENT_ONLY = {"o2m_launch_timing", "o2m_launch_timing_read"}  # C-ABI entries without a torch.ops.o2m twin
+MEASUREMENT_ONLY = {"o2m_launch_timing", "o2m_launch_timing_read", "o2m_debug_fill_blocks"}  # C-ABI entries without a torch.ops.o2m twin
 
 
 class LaunchStat(C.Structure):
@@ -123,6 +124,12 @@ def launch_timing(enable: bool) -> bool:
     """Switch the library's per-kernel launch timing (HIP-event pairs inside the launch sites, on the
     launch stream) on or off; returns the previous state.  bench.py's roofline object uses it."""
     return bool(lib().o2m_launch_timing(int(bool(enable))))
+
+
+def debug_fill_blocks(n: int) -> int:
+    """Test hook (include/o2m_hip.h): the tile count o2m_conv2d_fwd's kernel selection takes for "one workgroup per
+    CU"; n <= 0 restores 256.  Returns the previous value."""
+    return int(lib().o2m_debug_fill_blocks(int(n)))
 
 
 def launch_timing_read(capacity: int = 64):

@@ -28,7 +28,9 @@
 namespace {
 
 constexpr int BK = 64;  // reduction elements per stage (one 128-B LDS row of bf16)
-constexpr long kFillBlocks = 256;  // one block per CU
+constexpr long kFillBlocksDefault = 256;  // one block per CU
+long g_fill_blocks = kFillBlocksDefault;   // o2m_debug_fill_blocks (test hook): routes small parity cases to the big tiles
+#define kFillBlocks g_fill_blocks
 
 // Byte offset of 16-B slot (row, chunk) in a [rows][64] bf16 tile.  Two 128-B rows share a
 // 256-B bank row; XOR with (row>>1)&15 spreads each ds_read_b128 lane group (same chunk,
@@ -1477,6 +1479,12 @@ extern "C" int o2m_conv2d_dots_finalize(const float* partial, float* dots, int32
                      partial, dots, B * C, C, nchunks);
   O2M_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int32_t o2m_debug_fill_blocks(int32_t n) {
+  const long prev = g_fill_blocks;
+  g_fill_blocks = n > 0 ? n : kFillBlocksDefault;
+  return (int32_t)prev;
 }
 
 extern "C" int32_t o2m_conv2d_stats_rows(const o2m_conv_desc* d) {

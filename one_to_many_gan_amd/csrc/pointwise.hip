@@ -1096,7 +1096,7 @@ void close(int slot, hipStream_t s) {
 
 extern "C" {
 
-int o2m_abi_version(void) { return 19; }
+int o2m_abi_version(void) { return 20; }
 
 int32_t o2m_launch_timing(int32_t enable) {
   std::lock_guard<std::mutex> lock(o2m_timing::g_mu);

@@ -697,6 +697,7 @@ class _ConvFn(torch.autograd.Function):
         ctx.norm_follows = stats_eps is not None
         ctx.counted = prep.note_forward_use(ctx.needs_input_grad[1])
         ctx.ts_params = (ts_weight, ts_bias)
+        ctx.bias_param = bias
         ctx.has_bias, ctx.has_res = bias is not None, residual is not None
         ctx.save_for_backward(x, y, residual, s, d, weight, bias_p, wv, ws)
         if stats_eps is not None:
@@ -767,6 +768,13 @@ class _ConvFn(torch.autograd.Function):
             # backward) has zero mean over the pixels of every (sample, channel), so its sum is exactly 0
             # -- the reference's value there is rounding noise.  No reduction pass.
             g_bias = None  # (no gradient = the zero the optimiser's zero_grad left in place)
+            # no AccumulateGrad node runs for this parameter, so its post-accumulate hook never fires: tell the
+            # data-parallel reducer here that the (zero) gradient is complete -- otherwise the bucket segment that
+            # holds the bias, and every earlier one behind it, would wait for the end of backward (dist.BucketReducer
+            # launches segments strictly last to first; its ``seen`` set ignores repeats of a multiply used layer)
+            hook = GRAD_READY_HOOKS.get(ctx.bias_param)
+            if hook is not None:
+                hook(ctx.bias_param)
         elif ctx.has_bias and need_b:
             if act == H.ACT_NONE and d is None:  # reduce-only pass over g (one read, nothing stored)
                 H.act_bwd_reduce(g, None, None, None, None, sums, H.ACT_NONE)

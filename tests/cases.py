@@ -74,14 +74,24 @@ def _grads(module, out, tag):
             out[f"g/{name}"] = _cpu(p.grad)
 
 
-def _run_op(module, inputs, tag, device, call=None, wrap=None):
-    """Forward + backward of one module under the fixed linear loss sum(y * r)."""
+def _run_op(module, inputs, tag, device, call=None, wrap=None, sub=False):
+    """Forward + backward of one module under the fixed linear loss sum(y * r).  ``sub``: full-size cases (the
+    shapes the big tiles are selected at) commit a strided subsample + moments of every tensor (``_sub``)."""
     module = module.to(device)
     target = wrap(module) if wrap else module
     xs = [x.to(device).requires_grad_(True) for x in inputs]
     y = call(target, *xs) if call else target(*xs)
     r = sym_uniform(f"{tag}/r", y.shape).to(device)
     (y.float() * r).sum().backward()
+    if sub:
+        out = OrderedDict()
+        _put(out, "y", y)
+        for i, x in enumerate(xs):
+            _put(out, f"gx{i}", x.grad)
+        for name, p in module.named_parameters():
+            if p.grad is not None:
+                _put(out, f"g/{name}", p.grad)
+        return out
     out = OrderedDict(y=_cpu(y))
     for i, x in enumerate(xs):
         out[f"gx{i}"] = _cpu(x.grad)
@@ -123,18 +133,18 @@ def case_resample(ns, device, *, tag, kind, n, c, h, w):
     return _run_op(m, [x], tag, device)
 
 
-def case_resblock(ns, device, *, tag, dim, n, h, w):
+def case_resblock(ns, device, *, tag, dim, n, h, w, sub=False):
     m = ns.resblock(dim)
     fill_state_dict(m, tag)
-    return _run_op(m, [image_batch(f"{tag}/x", (n, dim, h, w))], tag, device)
+    return _run_op(m, [image_batch(f"{tag}/x", (n, dim, h, w))], tag, device, sub=sub)
 
 
-def case_modresblock(ns, device, *, tag, dim, wdim, n, h, w):
+def case_modresblock(ns, device, *, tag, dim, wdim, n, h, w, sub=False):
     m = ns.modresblock(dim, wdim)
     fill_state_dict(m, tag)
     x = image_batch(f"{tag}/x", (n, dim, h, w))
     s = unit_uniform(f"{tag}/w", (n, wdim))
-    return _run_op(m, [x, s], tag, device)
+    return _run_op(m, [x, s], tag, device, sub=sub)
 
 
 # ----------------------------------------------------------------------------- net cases
@@ -406,6 +416,12 @@ _reg("down_odd2", case_resample, kind="down", n=1, c=16, h=63, w=9)
 _reg("resblock", case_resblock, dim=8, n=2, h=9, w=10)
 _reg("modresblock", case_modresblock, dim=8, wdim=6, n=2, h=9, w=9)
 _reg("resblock_c128", case_resblock, dim=128, n=1, h=16, w=16)
+# The residual blocks of the 256 x 256 step AT THEIR REAL SIZE (256 channels, 64 x 64 latent, B = 16 = 256 tiles of
+# 256 x 256): the shapes at which the phase-pipelined igemm (InstanceNorm-partial epilogue, reflect fold, residual
+# gradient through BlockLink), the phase-pipelined weight gradient and the batched style path are SELECTED -- every
+# smaller case runs the generic tiles.  ~10 s each on the CPU oracle; outputs subsampled (tests/cases.py::_sub).
+_reg("resblock_c256_b16", case_resblock, dim=256, n=16, h=64, w=64, sub=True)
+_reg("modresblock_c256_b16", case_modresblock, dim=256, wdim=6, n=16, h=64, w=64, sub=True)
 _reg("gen32", case_generator, nc=3, size=32, min_latent=8, n_res=3, start_filters=8, n=2)
 _reg("gen64_gray", case_generator, nc=1, size=64, min_latent=64, n_res=7, start_filters=16, n=1)
 # BASELINE config #4's topology (512x512: 3 downsamples, 512-channel latent) at a size the CPU finishes

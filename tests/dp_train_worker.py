@@ -38,9 +38,11 @@ def main(out_dir):
                              resume=ck, log=lines.append, data_parallel=True, image_grids=False)
     torch.cuda.synchronize()
     sums2 = {k: float(o.bucket.flat.double().sum()) for k, o in opts2.items()}
+    # how each bucket segment's all-reduce of the last step was launched: "hook" = from inside backward
+    logs = {k: [why for _, why in o.pre_step_hooks[0].__self__.last_launch_log] for k, o in opts2.items()}
     with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
         json.dump({"after2": sums, "after3": sums2, "logged": len([l for l in lines if l.startswith("Step: ")]),
-                   "step": float(opts2["G"].step_t)}, f)
+                   "step": float(opts2["G"].step_t), "launch_logs": logs}, f)
     dist.barrier()
     dist.destroy_process_group()
 

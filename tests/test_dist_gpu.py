@@ -54,6 +54,15 @@ def test_train_loop_under_data_parallelism(tmp_path):
     assert a["after2"] == b["after2"] and a["after3"] == b["after3"], (a, b)
     assert a["after2"] != a["after3"] and a["step"] == b["step"] == 3.0
     assert a["logged"] == 3 and b["logged"] == 0  # 2 + 1 log lines, rank 0 only
+    # the dead biases ahead of InstanceNorm (D / S model.3/7/11.bias, G encoder.1/4/8.bias) get no
+    # AccumulateGrad node; unless the conv's backward reports them complete, their bucket segment -- and, segments
+    # going out strictly last to first, every earlier one -- waits for FusedAdam.step instead of overlapping
+    # backward.  On the real networks every segment of D and S must have been launched from inside backward.
+    for rank_out in (a, b):
+        logs = rank_out["launch_logs"]
+        assert logs["D"] and logs["S"] and logs["G"], logs
+        assert set(logs["D"]) == {"hook"} and set(logs["S"]) == {"hook"}, logs
+        assert logs["G"].count("hook") >= len(logs["G"]) - 1, logs
     models = sorted(p.name for p in (tmp_path / "dp" / "models").iterdir())
     assert models == ["1.tar", "2.tar", "3.tar"]
     assert len((tmp_path / "dp" / "log").read_text().splitlines()) == 3

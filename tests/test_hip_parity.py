@@ -120,6 +120,59 @@ def test_fp8_mode_matches_oracle_and_fixture(name, golden_dir):
     _check(name, got, {k: gold[k] for k in gold.files}, "fp8", "reference fixture")
 
 
+def _timed_case(name, precision):
+    """run_case with the library's launch timer on: (outputs, names of the MFMA conv kernels that ran)."""
+    from one_to_many_gan_amd import _hip as H
+
+    H.launch_timing(True)
+    try:
+        got = run_case(name, product_ns(precision), "cuda")
+        names = set(H.launch_timing_read(256))
+    finally:
+        H.launch_timing(False)
+    return got, names
+
+
+@pytest.mark.parametrize("name", ["resblock_c256_b16", "modresblock_c256_b16"])
+def test_full_size_blocks_reach_the_phase_pipelined_kernels(name):
+    """VERDICT r3 #1a: the 256-channel residual blocks at B = 16, 64 x 64 -- the oracle / fixture comparison of
+    test_hip_matches_oracle_and_fixture above is only worth its name if the kernels the STEP selects at this shape are
+    the ones that ran: the phase-pipelined igemm (forward with the InstanceNorm-partial epilogue, data gradient with the
+    reflect fold and the residual gradient of BlockLink) and the phase-pipelined weight gradient."""
+    got, names = _timed_case(name, "bf16")
+    assert "conv_igemm_p8<bf16,256x256>" in names, names
+    assert "conv_wgrad_p8<bf16,256x256>" in names, names
+    _check(name, got, _oracle(name), "bf16", "oracle")
+
+
+# cases small enough for the CPU oracle whose layers the full-size step would hand to the phase-pipelined igemm
+# (Co > 128) and the halo-tile kernel (3 x 3, Co 64 / 128, rows of a multiple of 32 pixels) if only they had >= 256
+# (512) tiles: with the tile-count threshold lowered (o2m_debug_fill_blocks, a test hook of the C ABI) they ARE
+# handed to them -- partial tiles, tiny grids and per-sample filters included
+FORCED_OP_CASES = ["gen64_deep", "resblock_c128", "modconv_c128", "conv3_c128"]
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+@pytest.mark.parametrize("name", FORCED_OP_CASES)
+def test_small_cases_routed_to_the_big_tile_kernels_match_oracle_and_fixture(name, precision, golden_dir):
+    """VERDICT r3 #1b.  bf16: the p8 / halo kernels under the oracle and the reference fixture; fp32: the same routing
+    decisions taken for the fp32-split tiles (256 x 256 symmetric kernel instead of 128 x 128)."""
+    from one_to_many_gan_amd import _hip as H
+
+    prev = H.debug_fill_blocks(1)
+    try:
+        got, names = _timed_case(name, precision)
+    finally:
+        H.debug_fill_blocks(prev)
+    if precision == "bf16":
+        assert any(n.startswith("conv_igemm_p8") or n.startswith("conv3x3_halo") for n in names), names
+        if name == "gen64_deep":
+            assert {"conv_igemm_p8<bf16,256x256>", "conv3x3_halo<bf16,8x32x64>", "conv3x3_halo<bf16,8x32x128>"} <= names, names
+    _check(name, got, _oracle(name), precision, "oracle")
+    gold = np.load(os.path.join(golden_dir, f"{name}.npz"))
+    _check(name, got, {k: gold[k] for k in gold.files}, precision, "reference fixture")
+
+
 SHARED_MASK_CASES = [n for n in OP_CASES if n.startswith(NET_CASES)]
 # Measured on MI355X (tools/parity_report.py --shared-masks, profiles/r02_shared_masks_report.txt): with the
 # masks shared, the fp32-mode gradients sit this far from the fp64 oracle, per case (worst tensor).
@@ -153,7 +206,7 @@ def test_net_gradients_with_shared_activation_masks(name):
 # amount proportional to lr.  Measured round 2 (gpurun_out/r02/gputest1.log): probe/img 6.6e-2 in fp32 mode and 0.49 in
 # bf16; at lr 2e-5 (steps128, default bounds 5e-2 / 2e-1) the same code measures 1e-3 / 2e-2.  The logged losses
 # of BOTH steps stay on the default bounds in both cases.
-PROBE_TOL = {"steps128_stock": {"fp32": 0.2, "bf16": 1.0}}
+PROBE_TOL = {"steps128_stock": {"fp32": 0.2, "bf16": 0.7}}
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])

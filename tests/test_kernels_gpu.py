@@ -657,6 +657,54 @@ def test_halo_kernel_instance_norm_partials_match_the_statistics_pass(co):
 
 
 @pytest.mark.parametrize("reflect", [True, False], ids=["reflect", "zero"])
+def test_p8_kernel_instance_norm_partials_match_the_statistics_pass(reflect):
+    """The phase-pipelined 256 x 256 kernel's InstanceNorm partials at the shape the step selects it at (256 -> 256,
+    64 x 64, B = 32 = two rounds of 256 tiles): the accumulator-direct epilogue sums each wave's 128 pixels x 64 permuted
+    channels with DPP row rotations (conv_igemm.hip); through o2m_instnorm_finalize against the separate statistics pass
+    over y, and y itself against torch on the same bf16 operands.  The launch timer names the kernel that ran."""
+    import torch.nn.functional as F
+
+    from one_to_many_gan_amd import _hip as H
+
+    torch.manual_seed(16)
+    B, S, C = 32, 64, 256
+    x = torch.randn(B, S, S, C, device="cuda").bfloat16()
+    w = (torch.randn(C, 3, 3, C, device="cuda") / (3 * C ** 0.5)).bfloat16()
+    bias = torch.randn(C, device="cuda")
+    y = torch.empty(B, S, S, C, device="cuda", dtype=torch.bfloat16)
+    mode = H.PAD_REFLECT if reflect else H.PAD_ZERO
+    rows = H.conv2d_stats_rows(x, w, y, pad=1)
+    assert rows == 128
+    nchunks = S * S // rows
+    part = torch.full((B * nchunks * C * 2,), float("nan"), device="cuda")
+    H.launch_timing(True)
+    try:
+        H.conv2d_fwd(x, w, y, bias=bias, pad=1, pad_mode=mode, act=H.ACT_NONE, stats=part)
+        names = set(H.launch_timing_read())
+    finally:
+        H.launch_timing(False)
+    assert names == {"conv_igemm_p8<bf16,256x256>"}, names
+    mr = torch.empty(B, C, 2, device="cuda")
+    H.instnorm_finalize(part, mr, S * S, nchunks, 1e-5)
+    ws = torch.empty(H.instnorm_ws_floats(B, S * S, C), device="cuda")
+    mr0 = torch.empty(B, C, 2, device="cuda")
+    H.instnorm_stats(y, ws, mr0, 1e-5)
+    torch.cuda.synchronize()
+    assert torch.isfinite(mr).all()
+    assert float((mr[..., 0] - mr0[..., 0]).abs().max()) < 2e-3
+    assert float(((mr[..., 1] - mr0[..., 1]) / mr0[..., 1]).abs().max()) < 2e-3
+    # the map itself and the statistics against torch fp32 on the same operands (independent of both kernels)
+    xn = x[:4].float().permute(0, 3, 1, 2)
+    xn = F.pad(xn, (1, 1, 1, 1), mode="reflect" if reflect else "constant")
+    ref = F.conv2d(xn, w.float().permute(0, 3, 1, 2), bias)
+    got = y[:4].float().permute(0, 3, 1, 2)
+    assert float((got - ref).norm() / ref.norm()) < 4e-3
+    assert float((mr[:4, :, 0] - ref.mean((2, 3))).abs().max()) < 2e-3
+    rstd = (ref.var((2, 3), unbiased=False) + 1e-5).rsqrt()
+    assert float(((mr[:4, :, 1] - rstd) / rstd).abs().max()) < 2e-3
+
+
+@pytest.mark.parametrize("reflect", [True, False], ids=["reflect", "zero"])
 def test_phase_pipelined_weight_gradient_matches_torch(reflect):
     """conv_wgrad_p8_kernel (256 -> 256, 3 x 3, 64-pixel rows; transposing LDS reads, LDS-DMA fills, slabs) against
     torch's fp32 weight gradient of the same bf16-valued operands, for both paddings and an uneven last slice."""
