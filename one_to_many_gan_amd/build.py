@@ -20,7 +20,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libo2m_hip.so")
 TORCH_LIB = os.path.join(HERE, "lib", "libo2m_torch.so")
 SHIM = "torch_ops.cpp"
-SOURCES = ["conv_igemm.hip", "conv_wgrad.hip", "pointwise.hip", "style.hip", "ada.hip"]
+SOURCES = ["conv_igemm.hip", "conv_direct.hip", "conv_wgrad.hip", "pointwise.hip", "style.hip", "ada.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
          "-Wno-unused-value"]
 

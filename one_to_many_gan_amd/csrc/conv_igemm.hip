@@ -24,6 +24,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "conv_direct.h"
 
 namespace {
 
@@ -1397,6 +1398,8 @@ int launch_cfg(const o2m_conv_desc& d, hipStream_t s, long m_begin = 0, long m_e
 template <typename T>
 int launch_dtype(const o2m_conv_desc& d, hipStream_t s) {
   if constexpr (sizeof(T) == 2) {
+    if (o2m_direct::stem8_ok(d)) return o2m_direct::launch_stem8(d, s);
+    if (o2m_direct::fewout_ok(d)) return o2m_direct::launch_fewout(d, s);
     if (halo_ok(d)) return d.Co == 64 ? launch_halo<64>(d, s) : launch_halo<128>(d, s);
   }
   // big 8-wave tiles when they still give every CU a block; otherwise the 4-wave 128-wide
@@ -1450,6 +1453,7 @@ int launch_dtype(const o2m_conv_desc& d, hipStream_t s) {
 // (mirrors launch_dtype below)
 static int stats_rows_for(const o2m_conv_desc& d) {
   if (d.stride > 1 || d.in_scale) return 0;
+  if (d.dtype == O2M_BF16 && o2m_direct::stem8_ok(d)) return o2m_direct::stem8_stats_rows(d);  // whole output rows of a block
   if (d.dtype == O2M_BF16 && halo_ok(d)) return 64;  // one partial per wave row of an 8 x 32 tile
   if (d.Co > 128) {
     if (tiles_for<256, 256>(d) >= kFillBlocks) return 128;  // p8 and the symmetric 256x256 kernel alike

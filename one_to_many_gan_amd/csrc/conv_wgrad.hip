@@ -92,6 +92,24 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* a) {
   return __builtin_bit_cast(bf16x8, r);
 }
 
+// ds_read_b64_tr_b16 as INLINE ASM.  Through the builtin, hipcc (ROCm 7.2) puts an `s_waitcnt vmcnt(0)` in front of every
+// group of transposing reads that follows an LDS-DMA fill (the builtin's memory operand carries no alias information, so
+// SIInsertWaitcnts assumes it may read what the DMA writes): the counted-vmcnt prefetch of the phase-pipelined kernels
+// below was drained at every phase that reads fragments.  The asm form is invisible to that pass -- and to its lgkmcnt
+// bookkeeping: the caller waits (`lds_reads_done`) before the first MFMA that consumes the registers.
+typedef __attribute__((address_space(3))) char lds_char;
+__device__ __forceinline__ unsigned lds_addr(const char* p) { return (unsigned)(size_t)(lds_char*)p; }
+template <int OFF>
+__device__ __forceinline__ s16x4 ds_tr(unsigned a) {
+  s16x4 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF) : "memory");
+  return v;
+}
+__device__ __forceinline__ void lds_reads_done() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);  // MFMAs touch no memory: the clobber alone does not keep them behind the wait
+}
+
 template <typename T, int BCO, int BKO, int WAVES_CO, int WAVES_K, bool XS, bool GS, bool ALIGNED>
 __global__ __launch_bounds__(NT, 2) void conv_wgrad_kernel(const o2m_wgrad_desc d, int tiles_co,
                                                            int tiles_k, int rows_per_split) {
@@ -467,27 +485,35 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_p8_kernel(const o2m_wgrad_d
   const int fsw = (q << 1) | ((g & 1) << 3);
   const int fa0 = (8 * g + q) * 256 + (((8 * wrow + (pq >> 1)) ^ fsw) << 4) + 8 * (pq & 1);
   const int fb0 = (8 * g + q) * 256 + (((4 * wcol + (pq >> 1)) ^ fsw) << 4) + 8 * (pq & 1) + 4 * REG;
-  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-  auto tr8 = [&](const char* a) {  // 8 consecutive pixel rows of this lane's column: two transposing reads
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 1024));
+  // (inline-asm transposing reads: through the builtin the compiler drained the counted fill prefetch -- `s_waitcnt
+  // vmcnt(0)` -- in front of every fragment read; see ds_tr above.  The waits for the reads themselves are in
+  // WP8_WAIT_AND_SYNC.)
+  const unsigned lb = lds_addr(smem);
+  auto tr8 = [&](const unsigned a, auto off) {  // 8 consecutive pixel rows of this lane's column: two transposing reads
+    constexpr int O = decltype(off)::value;
+    const s16x4 lo = ds_tr<O>(a), hi = ds_tr<O + 1024>(a);
     const s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8, r);
   };
+  using std::integral_constant;
   bf16x8 af[4][2], b0f[2][2], b1f[2][2];
   auto read_a = [&](int buf, int mh) {
-    const char* base = smem + (2 * mh + buf) * REG;
+    const unsigned base = lb + (unsigned)((2 * mh + buf) * REG);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) af[i][ks] = tr8(base + ((fa0 ^ (i << 5)) + ks * 8192));
+    for (int i = 0; i < 4; ++i) {
+      const unsigned a = base + (unsigned)(fa0 ^ (i << 5));
+      af[i][0] = tr8(a, integral_constant<int, 0>{});
+      af[i][1] = tr8(a, integral_constant<int, 8192>{});
+    }
   };
   auto read_b = [&](bf16x8 (&bf)[2][2], int buf, int nh) {
-    const char* base = smem + (2 * nh + buf) * REG;
+    const unsigned base = lb + (unsigned)((2 * nh + buf) * REG);
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) bf[j][ks] = tr8(base + ((fb0 ^ (j << 5)) + ks * 8192));
+    for (int j = 0; j < 2; ++j) {
+      const unsigned a = base + (unsigned)(fb0 ^ (j << 5));
+      bf[j][0] = tr8(a, integral_constant<int, 0>{});
+      bf[j][1] = tr8(a, integral_constant<int, 8192>{});
+    }
   };
 
   f32x4 acc[8][4];
@@ -506,10 +532,11 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_p8_kernel(const o2m_wgrad_d
           acc[mh * 4 + i][nh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][ks], bf[j][ks], acc[mh * 4 + i][nh * 2 + j], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
   };
-#define WP8_WAIT_AND_SYNC()                                 \
-  do {                                                      \
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        \
-    __builtin_amdgcn_s_barrier();                           \
+#define WP8_WAIT_AND_SYNC()                                         \
+  do {                                                              \
+    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");     \
+    __builtin_amdgcn_s_barrier();                                   \
+    __builtin_amdgcn_sched_barrier(0);                              \
   } while (0)
 
   // ---- prologue / main loop: the schedule of conv_igemm_p8_kernel, region for region ----------------------
@@ -552,7 +579,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_p8_kernel(const o2m_wgrad_d
   }
 #undef WP8_WAIT_AND_SYNC
   if (wrow == 0) __builtin_amdgcn_s_barrier();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the zero fills issued past the end of the reduction
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the fills issued past the end of the reduction (and the
+                                                               // last prefetched B0 fragments: asm reads, see ds_tr)
   __syncthreads();
 
   // ---- epilogue: fp32 tile through LDS -> the slice's slab, whole 16-B vectors of a filter row ---------------
@@ -585,6 +613,191 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_p8_kernel(const o2m_wgrad_d
       __builtin_amdgcn_s_barrier();
     }
   }
+}
+
+// =============================================================================================
+// Halo-tile weight gradient ("wgrad h3") for the 3 x 3, zero-padded, 64- / 128-channel layers at large maps (the
+// 64 <-> 128 layers at 256 x 256 and the 128 <-> 256 layers at 128 x 128 of the generator: ~40 % of the step's
+// weight-gradient time).  The register-staged tiles above reduce ONE filter tap per block: the input row block is
+// fetched once per tap -- nine L2 -> LDS trips per element, 43-64 FLOP per ingested byte -- and they sit on the
+// L2 -> LDS ingest limit at 0.24-0.33 of the MFMA peak (profiles/r02_c_pmc_wgrad_co64.json).  Here a block owns an
+// 8 x 32 tile of pixels of one sample at a time and a (64 output channels) x (64 input channels) block of the filter
+// for ALL NINE taps:
+//   C[co][tap][ci] += sum_{px in tile} G[px][co] * X[px (+) tap][ci]
+// with the G tile (256 px x 128 B) and the 10 x 34 input patch (340 px x 128 B) resident in LDS: every element is
+// ingested once per tile (x: + the 1.33x halo), 250 FLOP per ingested byte.  A k-step = one 32-pixel tile row under
+// one tap; the reduction index (pixels) is the SLOW index of both LDS images (NHWC as in HBM, LDS-DMA fills), so the
+// fragments come out with ds_read_b64_tr_b16 as in the kernels above.  The 8 k-values of a lane are pixels
+// 4 g + 0..3 and 16 + 4 g + 0..3 of the row (the MFMA does not care which pixel is which k as long as both operands
+// agree): a half-wave read then touches 8 CONSECUTIVE pixel rows, and the 16-B chunks of pixel row pp are XOR-swizzled
+// with ((pp >> 1) & 3) << 1 (source side of the DMA) so that those 8 rows' 32-B windows cover all eight 32-B windows
+// of the 256-B bank row, at ANY tap shift.
+//  * 8 waves = 2 (co tile pairs) x 4 (ci tiles of 16): a wave holds 2 x 9 accumulator tiles (72 registers) -- its two G
+//    fragments of a tile row serve all nine taps, one X fragment per tap;
+//  * fully unrolled over the tile's 8 rows and 9 taps: every fragment address is a lane-constant register (one per
+//    tap column and value of (row + ky) & 3: 12 for X, 2 for G) plus an immediate -- no address arithmetic in the loop;
+//  * ONE block per CU with TWO tile buffers (2 x 75 KB of LDS): the fills of tile t + 1 are issued before the MFMAs of
+//    tile t and waited for after them -- one barrier per tile.  (The two-blocks-per-CU form of conv3x3_halo_kernel needs
+//    <= 128 VGPRs; this kernel wants 162 -- 72 accumulators, 14 address registers, fragments in flight -- and spilled.)
+//  * a block walks its slice of the tiles, then stores its 64 x 9 x 64 fp32 partial to its slice's slab;
+//    wgrad_reduce_kernel adds the slices in order (bitwise reproducible).
+// =============================================================================================
+__global__ __launch_bounds__(512, 2) void conv_wgrad_halo_kernel(const o2m_wgrad_desc d, const int tiles_per_slice) {
+  constexpr int PW = 34, NPIX = 10 * PW, PFILLS = (NPIX + 7) / 8;  // 340 patch pixels, 43 fills of 8
+  constexpr int PATCH_B = PFILLS * 1024, G_B = 256 * 128;           // 44032 + 32768 bytes
+  constexpr int TILE_B = PATCH_B + G_B;                             // one tile buffer
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+  const int H = d.H, W = d.W, Ci = d.Ci, Co = d.Co;
+  const int K = 9 * Ci;
+  const int nci = Ci >> 6, pairs = (Co >> 6) * nci;
+  const int bid = xcd_tile_order(blockIdx.x, gridDim.x);  // the filter blocks of one slice share G and x: one XCD
+  const int pair = bid % pairs, slice = bid / pairs;
+  const int co0 = (pair / nci) << 6, ci0 = (pair % nci) << 6;
+  const int tiles_x = W >> 5, tpi = tiles_x * (H >> 3), total = d.B * tpi;
+  const int t_begin = slice * tiles_per_slice, t_end = min(total, t_begin + tiles_per_slice);
+  const rsrc_t xr = make_rsrc(d.x, (unsigned)((size_t)d.B * H * W * Ci * 2));
+  const rsrc_t gr = make_rsrc(d.gy, (unsigned)((size_t)d.B * H * W * Co * 2));
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+
+  // ---- fills: a wave-instruction fills 8 pixels x 128 B; lane l owns slot (l & 7) of pixel 8 f + (l >> 3) and fetches
+  // the chunk the swizzle maps there.  Offsets are recomputed per tile (the kernel must fit 128 VGPRs).
+  auto issue_tile = [&](int t, int buf) {
+    const int b = t / tpi, tis = t - b * tpi;
+    const int ty0 = (tis / tiles_x) << 3, tx0 = (tis % tiles_x) << 5;
+    char* patch = smem + buf * TILE_B;
+    char* gbuf = patch + PATCH_B;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));  // keeps the offset arithmetic inside the tile loop
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int f = 8 * j + wave;
+      if (f >= PFILLS) continue;  // wave-uniform
+      const int pp = 8 * f + (ln >> 3);
+      const int c = (ln & 7) ^ (((pp >> 1) & 3) << 1);
+      const int py = pp / PW, px = pp - py * PW;
+      const int gy = ty0 + py - 1, gx = tx0 + px - 1;
+      const bool ok = pp < NPIX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      const unsigned off = ok ? (unsigned)(((b * H + gy) * W + gx) * Ci + ci0 + c * 8) * 2u : OOB_OFF;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void*)(patch + f * 1024), 16, (int)off, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int f = 8 * j + wave;  // tile pixels 8 f .. 8 f + 7: row f >> 2, columns 8 (f & 3) ..
+      const int pp = 8 * f + (ln >> 3);
+      const int c = (ln & 7) ^ (((pp >> 1) & 3) << 1);
+      const unsigned off = (unsigned)(((b * H + ty0 + (pp >> 5)) * W + tx0 + (pp & 31)) * Co + co0 + c * 8) * 2u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(gr, (lds_void*)(gbuf + f * 1024), 16, (int)off, 0, 0, 0);
+    }
+  };
+
+  // ---- fragment addresses (transposing reads): lane = 16 g + 4 q + p ---------------------------------------------
+  // k-group g of a 32-pixel row: pixels 4 g + 0..3 (first read) and 16 + 4 g + 0..3 (second read: + 16 x 128 B);
+  // q: pixel inside the group of four; p: column quad (4 channels = 8 B) of the 16-channel tile
+  const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+  const int ct0 = 2 * (wave >> 2), cit = wave & 3;  // this wave's two co tiles (16 each) and its ci tile
+  const int pg = 4 * g + q;                          // pixel of the first read inside the row
+  // G image: pixel row index 32 r + pg (+ 16): swizzle ((pix >> 1) & 3) is a lane constant
+  const int ga0 = PATCH_B + pg * 128 + (((2 * ct0 + (p >> 1)) ^ (((pg >> 1) & 3) << 1)) << 4) + 8 * (p & 1);
+  const int ga1 = ga0 ^ 32;  // co tile ct0 + 1: the next 32-B window (ct0 is even)
+  // patch image: pixel (r + ky) * 34 + kx + pg (+ 16); ((pp >> 1) & 3) = ((r + ky) + ((kx + pg) >> 1)) & 3
+  int xa[3][4];
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+      xa[kx][v] = (kx + pg) * 128 + (((2 * cit + (p >> 1)) ^ (((v + ((kx + pg) >> 1)) & 3) << 1)) << 4) + 8 * (p & 1);
+
+  f32x4 acc[2][9];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragments of one tile row: the two G fragments and the nine shifted X fragments (inline-asm reads: ds_tr above)
+  struct RowFrags { bf16x8 a0, a1, x[9]; };
+  auto join = [](s16x4 lo, s16x4 hi) {
+    const s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, r);
+  };
+  const unsigned lbase = lds_addr(smem);
+  auto read_row = [&](RowFrags& f, const unsigned tb, auto rc) {  // rc: std::integral_constant row index
+    constexpr int r = decltype(rc)::value;
+    f.a0 = join(ds_tr<r * 4096>(tb + ga0), ds_tr<r * 4096 + 2048>(tb + ga0));
+    f.a1 = join(ds_tr<r * 4096>(tb + ga1), ds_tr<r * 4096 + 2048>(tb + ga1));
+    // (the offsets are immediates of the asm: nine spelled-out calls, tap = 3 ky + kx)
+    f.x[0] = join(ds_tr<(r + 0) * PW * 128>(tb + xa[0][(r + 0) & 3]), ds_tr<(r + 0) * PW * 128 + 2048>(tb + xa[0][(r + 0) & 3]));
+    f.x[1] = join(ds_tr<(r + 0) * PW * 128>(tb + xa[1][(r + 0) & 3]), ds_tr<(r + 0) * PW * 128 + 2048>(tb + xa[1][(r + 0) & 3]));
+    f.x[2] = join(ds_tr<(r + 0) * PW * 128>(tb + xa[2][(r + 0) & 3]), ds_tr<(r + 0) * PW * 128 + 2048>(tb + xa[2][(r + 0) & 3]));
+    f.x[3] = join(ds_tr<(r + 1) * PW * 128>(tb + xa[0][(r + 1) & 3]), ds_tr<(r + 1) * PW * 128 + 2048>(tb + xa[0][(r + 1) & 3]));
+    f.x[4] = join(ds_tr<(r + 1) * PW * 128>(tb + xa[1][(r + 1) & 3]), ds_tr<(r + 1) * PW * 128 + 2048>(tb + xa[1][(r + 1) & 3]));
+    f.x[5] = join(ds_tr<(r + 1) * PW * 128>(tb + xa[2][(r + 1) & 3]), ds_tr<(r + 1) * PW * 128 + 2048>(tb + xa[2][(r + 1) & 3]));
+    f.x[6] = join(ds_tr<(r + 2) * PW * 128>(tb + xa[0][(r + 2) & 3]), ds_tr<(r + 2) * PW * 128 + 2048>(tb + xa[0][(r + 2) & 3]));
+    f.x[7] = join(ds_tr<(r + 2) * PW * 128>(tb + xa[1][(r + 2) & 3]), ds_tr<(r + 2) * PW * 128 + 2048>(tb + xa[1][(r + 2) & 3]));
+    f.x[8] = join(ds_tr<(r + 2) * PW * 128>(tb + xa[2][(r + 2) & 3]), ds_tr<(r + 2) * PW * 128 + 2048>(tb + xa[2][(r + 2) & 3]));
+  };
+  auto multiply = [&](const RowFrags& f) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a0, f.x[t], acc[0][t], 0, 0, 0);
+      acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a1, f.x[t], acc[1][t], 0, 0, 0);
+    }
+  };
+  using std::integral_constant;
+
+  if (t_begin < t_end) issue_tile(t_begin, 0);
+#pragma unroll 1
+  for (int t = t_begin; t < t_end; ++t) {
+    const int buf = (t - t_begin) & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's fills of tile t have landed ...
+    __syncthreads();                                   // ... everybody's have, and everybody is done with tile t - 1
+    if (t + 1 < t_end) issue_tile(t + 1, buf ^ 1);     // into the buffer tile t - 1 was read from
+    const unsigned tb = lbase + (unsigned)(buf * TILE_B);
+    // rows software-pipelined by one: the reads of row r + 1 are in flight under the 18 MFMAs of row r
+    RowFrags fa, fb;
+    read_row(fa, tb, integral_constant<int, 0>{});
+    lds_reads_done();
+    read_row(fb, tb, integral_constant<int, 1>{}); multiply(fa); lds_reads_done();
+    read_row(fa, tb, integral_constant<int, 2>{}); multiply(fb); lds_reads_done();
+    read_row(fb, tb, integral_constant<int, 3>{}); multiply(fa); lds_reads_done();
+    read_row(fa, tb, integral_constant<int, 4>{}); multiply(fb); lds_reads_done();
+    read_row(fb, tb, integral_constant<int, 5>{}); multiply(fa); lds_reads_done();
+    read_row(fa, tb, integral_constant<int, 6>{}); multiply(fb); lds_reads_done();
+    read_row(fb, tb, integral_constant<int, 7>{}); multiply(fa); lds_reads_done();
+    multiply(fb);
+  }
+
+  // ---- epilogue: C/D of 16x16x32: column = lane & 15 (ci), row = 4 (lane >> 4) + register (co) ---------------------
+  float* __restrict__ slab = d.slabs + (size_t)slice * Co * K;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+        slab[(size_t)(co0 + 16 * (ct0 + i) + 4 * g + rr) * K + t * Ci + ci0 + 16 * cit + (lane & 15)] = acc[i][t][rr];
+}
+
+// the layers the halo-tile weight gradient takes; *slices: its slicing of the pixel tiles
+inline bool wgrad_halo_ok(const o2m_wgrad_desc& d, long* slices, long* tiles_per_slice) {
+  static const int on = [] { const char* e = getenv("O2M_WGRAD_HALO"); return e ? atoi(e) : 1; }();
+  if (!on || d.dtype != O2M_BF16 || d.KH != 3 || d.KW != 3 || d.pad != 1 || d.pad_mode != O2M_PAD_ZERO || d.stride > 1 ||
+      d.in_scale || d.gy_scale || d.splits > 0 || d.Co % 64 || d.Ci % 64 || d.W % 32 || d.H % 8)
+    return false;
+  const long pairs = (long)(d.Co / 64) * (d.Ci / 64), total = (long)d.B * (d.H / 8) * (d.W / 32);
+  if (pairs > 64) return false;
+  if (total < 64) return false;  // (a few tiles: the register-staged tiles' splitting serves those)
+  long s = 256 / pairs;  // one resident block per CU
+  if (s < 1) s = 1;
+  long per = (total + s - 1) / s;
+  if (per < 8) per = 8;  // at least 8 tiles per block, to amortise its 147 KB partial
+  *tiles_per_slice = per;
+  *slices = (total + per - 1) / per;
+  return true;
 }
 
 // the layers the phase-pipelined weight-gradient kernel takes; *splits / *rows: its slicing of the image rows
@@ -687,6 +900,27 @@ int launch_wgrad_p8(const o2m_wgrad_desc& d, hipStream_t s, long splits, long ro
   return 0;
 }
 
+int launch_wgrad_halo(const o2m_wgrad_desc& d, hipStream_t s, long slices, long per, size_t* slab_floats) {
+  const int K = 9 * d.Ci;
+  if (slab_floats) {
+    *slab_floats = (size_t)slices * d.Co * K;
+    return 0;
+  }
+  constexpr int lds = 2 * (43 * 1024 + 256 * 128);  // two tile buffers
+  const long pairs = (long)(d.Co / 64) * (d.Ci / 64);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_halo_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  {
+    LaunchScope timed(s, 2.0 * d.B * d.H * d.W * d.Co * K, "%s", "conv_wgrad_halo<bf16,64x9x64>");
+    hipLaunchKernelGGL(conv_wgrad_halo_kernel, dim3((unsigned)(slices * pairs)), dim3(512), lds, s, d, (int)per);
+  }
+  O2M_LAUNCH_CHECK();
+  const long n4 = (long)d.Co * K / 4;
+  LaunchScope timed(s, 0.0, "%s", "wgrad_reduce");
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, d.dw, d.slabs, (int)slices, n4);
+  O2M_LAUNCH_CHECK();
+  return 0;
+}
+
 template <typename T>
 int launch_dtype(const o2m_wgrad_desc& d, hipStream_t s, size_t* slab_floats = nullptr) {
   if constexpr (sizeof(T) == 2) {
@@ -702,6 +936,17 @@ int launch_dtype(const o2m_wgrad_desc& d, hipStream_t s, size_t* slab_floats = n
         return 0;
       }
       if (d.slabs) return launch_wgrad_p8(d, s, splits, rows, nullptr);
+    }
+    long slices = 0, per = 0;
+    if (wgrad_halo_ok(d, &slices, &per)) {  // (slab mode only, like the p8 form; a size query reports the larger workspace)
+      if (slab_floats) {
+        size_t a = 0, b = 0;
+        (void)launch_wgrad_halo(d, s, slices, per, &a);
+        (void)launch_dtype_r2<T>(d, s, &b);
+        *slab_floats = a > b ? a : b;
+        return 0;
+      }
+      if (d.slabs) return launch_wgrad_halo(d, s, slices, per, nullptr);
     }
   }
   return launch_dtype_r2<T>(d, s, slab_floats);

@@ -82,9 +82,6 @@ def weights_epoch(p) -> tuple:
     return (_STATE["epoch"], getattr(p, "_o2m_epoch", 0))
 
 
-_NET_JOBS: dict = {}
-
-
 def prepare_network(module) -> None:
     """The kernel-side forms of EVERY filter of ``module`` in one launch (o2m_prepare_weights_batched) when all of
     them are stale -- the state right after the network's optimiser step -- instead of one launch per layer on
@@ -101,8 +98,13 @@ def prepare_network(module) -> None:
     if any(p.weight.dtype != torch.float32 or not p.weight.is_contiguous() for p in preps):
         return
     bufs = [p.buffers() for p in preps]
-    ident = tuple((p.weight.data_ptr(), b[3].data_ptr()) for p, b in zip(preps, bufs)) + (compute_dtype(),)
-    hit = _NET_JOBS.get(id(module))
+    # the cached job table holds raw device pointers: it is valid only while EVERY tensor it names is the one it was
+    # built for, and it lives on the module (a table keyed by id(module) outlived its module: a later network could
+    # get the same id -- and, from the caching allocator, the same parameter addresses -- with other buffer addresses,
+    # and the launch then wrote through stale pointers)
+    ident = tuple((p.weight.data_ptr(),) + tuple(t.data_ptr() for t in b if t is not None)
+                  for p, b in zip(preps, bufs)) + (compute_dtype(),)
+    hit = module.__dict__.get("_o2m_prep_jobs")
     if hit is None or hit[0] != ident:
         jobs, first = (H.PrepJob * len(preps))(), 0
         for j, (p, (w_f, w_d, q, full, qt)) in enumerate(zip(preps, bufs)):
@@ -111,7 +113,7 @@ def prepare_network(module) -> None:
                                 p.co, p.ci, p.kh * p.kw, p.cop, p.cip, p.c, first, 0)
             first += (p.cop * p.cip + 255) // 256
         raw = torch.frombuffer(bytearray(ctypes.string_at(ctypes.addressof(jobs), ctypes.sizeof(jobs))), dtype=torch.uint8)
-        hit = _NET_JOBS[id(module)] = (ident, raw.to(preps[0].weight.device), len(preps), first)
+        hit = module.__dict__["_o2m_prep_jobs"] = (ident, raw.to(preps[0].weight.device), len(preps), first)
     outs = [t for b in bufs for t in b if t is not None]
     with torch.no_grad():
         H.prepare_weights_batched(hit[1], hit[2], hit[3], compute_dtype(), outs)

