@@ -1466,12 +1466,21 @@ namespace {
 // dots[b][c] = sum over the row blocks of a sample of the epilogue's O2M_STATS_DOT partials, in block order
 __global__ __launch_bounds__(256) void dots_finalize_kernel(const float* __restrict__ partial, float* __restrict__ dots,
                                                             int BC, int C, int nchunks) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= BC) return;
-  const int b = idx / C, c = idx - b * C;
+  // 32 (sample, channel) pairs x 8 slices of the chunk list, slice sums added in slice order (as in_finalize_kernel)
+  __shared__ float red[8][32];
+  const int pi = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int idx = blockIdx.x * 32 + pi;
   float s = 0.f;
-#pragma unroll 8
-  for (int ch = 0; ch < nchunks; ++ch) s += partial[(((size_t)b * nchunks + ch) * C + c) * 2];
+  if (idx < BC) {
+    const int b = idx / C, c = idx - b * C;
+#pragma unroll 4
+    for (int ch = sl; ch < nchunks; ch += 8) s += partial[(((size_t)b * nchunks + ch) * C + c) * 2];
+  }
+  red[sl][pi] = s;
+  __syncthreads();
+  if (sl != 0 || idx >= BC) return;
+#pragma unroll
+  for (int k = 1; k < 8; ++k) s += red[k][pi];
   dots[idx] = s;
 }
 }  // namespace
@@ -1479,7 +1488,7 @@ __global__ __launch_bounds__(256) void dots_finalize_kernel(const float* __restr
 extern "C" int o2m_conv2d_dots_finalize(const float* partial, float* dots, int32_t B, int32_t C, int32_t nchunks,
                                         void* stream) {
   if (!partial || !dots || B <= 0 || C <= 0 || nchunks <= 0) return O2M_ERR_BAD_ARG;
-  hipLaunchKernelGGL(dots_finalize_kernel, dim3((B * C + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+  hipLaunchKernelGGL(dots_finalize_kernel, dim3((B * C + 31) / 32), dim3(256), 0, static_cast<hipStream_t>(stream),
                      partial, dots, B * C, C, nchunks);
   O2M_LAUNCH_CHECK();
   return 0;

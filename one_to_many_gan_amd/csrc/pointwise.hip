@@ -328,19 +328,34 @@ __global__ __launch_bounds__(NT) void in_partial_kernel(const T* __restrict__ x,
 }
 
 // MODE 0: -> {mean, rstd};  MODE 1: -> {mean gh, mean gh*xh}
+// 256 threads = 32 (sample, channel) pairs x 8 slices of the chunk list: a thread adds every 8th chunk's pair (8-byte
+// loads, 32 consecutive channels = 256 B per slice and chunk), the 8 slice sums meet in LDS in slice order -- a fixed
+// summation order as before, with an 8 times shorter dependent chain (the one-thread-per-pair form walked up to 1024
+// chunks serially: 13 us per launch, 51 launches per step).
 template <int MODE>
-__global__ void in_finalize_kernel(const float* partial, float* out, int B, int P, int C,
-                                   int nchunks, float eps) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= B * C) return;
-  const int b = idx / C, c = idx - b * C;
+__global__ __launch_bounds__(256) void in_finalize_kernel(const float* partial, float* out, int B, int P, int C,
+                                                          int nchunks, float eps) {
+  __shared__ float red[8][32][2];
+  const int pi = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int idx = blockIdx.x * 32 + pi;
   float s0 = 0.f, s1 = 0.f;
-#pragma unroll 8
-  for (int ch = 0; ch < nchunks; ++ch) {
-    const float* p = partial + (((size_t)b * nchunks + ch) * C + c) * 2;
-    s0 += p[0];
-    s1 += p[1];
+  if (idx < B * C) {
+    const int b = idx / C, c = idx - b * C;
+    const float* p = partial + (((size_t)b * nchunks + sl) * C + c) * 2;
+    const size_t step = (size_t)8 * C * 2;
+#pragma unroll 4
+    for (int ch = sl; ch < nchunks; ch += 8, p += step) {
+      const float2 v = *reinterpret_cast<const float2*>(p);
+      s0 += v.x;
+      s1 += v.y;
+    }
   }
+  red[sl][pi][0] = s0;
+  red[sl][pi][1] = s1;
+  __syncthreads();
+  if (sl != 0 || idx >= B * C) return;
+#pragma unroll
+  for (int k = 1; k < 8; ++k) { s0 += red[k][pi][0]; s1 += red[k][pi][1]; }
   const float inv = 1.f / (float)P;
   if (MODE == 0) {
     float mean = s0 * inv;
@@ -1273,7 +1288,7 @@ int o2m_instnorm_stats(const void* x, float* partial, float* mean_rstd, int32_t 
                                        (const T*)x, (const T*)nullptr, (const float*)nullptr, partial,
                                        P, C, 0, gm));
   O2M_LAUNCH_CHECK();
-  hipLaunchKernelGGL(in_finalize_kernel<0>, dim3((B * C + 255) / 256), dim3(256), 0, s, partial,
+  hipLaunchKernelGGL(in_finalize_kernel<0>, dim3((B * C + 31) / 32), dim3(256), 0, s, partial,
                      mean_rstd, B, P, C, gm.nchunks, eps);
   O2M_LAUNCH_CHECK();
   return 0;
@@ -1282,7 +1297,7 @@ int o2m_instnorm_stats(const void* x, float* partial, float* mean_rstd, int32_t 
 int o2m_instnorm_finalize(const float* partial, float* mean_rstd, int32_t B, int32_t P, int32_t C,
                           int32_t nchunks, float eps, void* stream) {
   if (!partial || !mean_rstd || B <= 0 || P <= 0 || C <= 0 || nchunks <= 0) return O2M_ERR_BAD_ARG;
-  hipLaunchKernelGGL(in_finalize_kernel<0>, dim3((B * C + 255) / 256), dim3(256), 0,
+  hipLaunchKernelGGL(in_finalize_kernel<0>, dim3((B * C + 31) / 32), dim3(256), 0,
                      static_cast<hipStream_t>(stream), partial, mean_rstd, B, P, C, nchunks, eps);
   O2M_LAUNCH_CHECK();
   return 0;
@@ -1313,7 +1328,7 @@ int o2m_instnorm_bwd(const void* g, const void* x, const float* mean_rstd, float
   DISPATCH_T(dtype, {
     hipLaunchKernelGGL((in_partial_kernel<T, 1>), dim3(gm.nchunks, B), dim3(NT), lds, s, (const T*)x,
                        (const T*)g, mean_rstd, partial, P, C, act, gm);
-    hipLaunchKernelGGL(in_finalize_kernel<1>, dim3((B * C + 255) / 256), dim3(256), 0, s, partial,
+    hipLaunchKernelGGL(in_finalize_kernel<1>, dim3((B * C + 31) / 32), dim3(256), 0, s, partial,
                        gsums, B, P, C, gm.nchunks, 0.f);
     hipLaunchKernelGGL((in_apply_kernel<T, 1>), dim3(gm.nchunks, B), dim3(NT), 0, s, (const T*)x,
                        (const T*)g, mean_rstd, gsums, (const T*)nullptr, (T*)gx, P, C, act, gm);
@@ -1377,7 +1392,7 @@ int o2m_instnorm_resample_bwd(const void* g_coarse, const void* x, const float* 
   DISPATCH_T(dtype, {
     hipLaunchKernelGGL((in_partial_kernel<T, 1, 2>), dim3(gm.nchunks, B), dim3(NT), lds, s, (const T*)x, (const T*)g_coarse,
                        mean_rstd, partial, P, C, act, gm, tp);
-    hipLaunchKernelGGL(in_finalize_kernel<1>, dim3((B * C + 255) / 256), dim3(256), 0, s, partial, gsums, B, P, C,
+    hipLaunchKernelGGL(in_finalize_kernel<1>, dim3((B * C + 31) / 32), dim3(256), 0, s, partial, gsums, B, P, C,
                        gm.nchunks, 0.f);
     hipLaunchKernelGGL((in_apply_kernel<T, 1, 2>), dim3(gm.nchunks, B), dim3(NT), 0, s, (const T*)x, (const T*)g_coarse,
                        mean_rstd, gsums, (const T*)nullptr, (T*)gx, P, C, act, gm, tp);

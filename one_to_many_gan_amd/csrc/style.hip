@@ -146,15 +146,43 @@ __global__ __launch_bounds__(NT) void style_bwd_batch_kernel(const float* gs, co
     return;
   }
   if (!gq) return;
-  const int o = blockIdx.x - param_blocks - B;  // one block per output channel row of gq
-  for (int i = threadIdx.x; i < Cip; i += NT) {
-    float a = 0.f;
-#pragma unroll 8
-    for (int b = 0; b < B; ++b) {
-      const float sv = s[(size_t)b * Cip + i];
-      a += e[(size_t)b * Cop + o] * sv * sv;
+  // dL/dQ[o][i] += sum_b e[b][o] * s[b][i]^2: a block takes EIGHT rows o (their e values in LDS), so a thread squares
+  // s[b][i] once per sample for eight accumulators -- the one-row-per-block form re-read the whole s table per row
+  // (2 B loads per thread and row in six dependent batches: most of this launch's 26 us)
+  __shared__ float es[8][64];
+  const int o0 = (blockIdx.x - param_blocks - B) * 8;
+  float a[2][8];  // (Cip <= 2 NT: checked by the launcher)
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) a[k][r] = 0.f;
+  for (int b0 = 0; b0 < B; b0 += 64) {
+    const int nb = min(64, B - b0);
+    __syncthreads();
+    for (int t = threadIdx.x; t < 8 * nb; t += NT) {
+      const int r = t / nb, bb = t - r * nb;
+      es[r][bb] = o0 + r < Cop ? e[(size_t)(b0 + bb) * Cop + o0 + r] : 0.f;
     }
-    atomicAdd(gq + (size_t)o * Cip + i, a);  // accumulates over the uses of the layer in one backward (see above)
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int i = threadIdx.x + k * NT;
+      if (i >= Cip) continue;
+#pragma unroll 4
+      for (int bb = 0; bb < nb; ++bb) {
+        const float sv = s[(size_t)(b0 + bb) * Cip + i], s2 = sv * sv;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) a[k][r] += es[r][bb] * s2;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int i = threadIdx.x + k * NT;
+    if (i >= Cip) continue;
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+      if (o0 + r < Cop) atomicAdd(gq + (size_t)(o0 + r) * Cip + i, a[k][r]);  // accumulates over the uses of the layer (see above)
   }
 }
 
@@ -180,13 +208,14 @@ int o2m_style_bwd(const float* sums, const float* bias, const float* dots, const
   if (!dots || !s || !w || !Ws || !gs || !gw || !gWs || !gbs) return O2M_ERR_BAD_ARG;
   if (B <= 0 || WD <= 0 || WD > MAXWD || Ci <= 0 || Cip < Ci || Cop <= 0) return O2M_ERR_BAD_ARG;
   if (d && (!sums || !Q || !e || !gq)) return O2M_ERR_BAD_ARG;
+  if (d && Cip > 2 * NT) return O2M_ERR_UNSUPPORTED;  // (the dL/dQ rows: two input channels per thread)
   hipStream_t st = static_cast<hipStream_t>(stream);
   const size_t lds = (Cop + 256) * sizeof(float);
   hipLaunchKernelGGL(style_bwd_sample_kernel, dim3(B, (Cip + 63) / 64), dim3(NT), lds, st, sums, bias, dots, s, d,
                      Q, e, gs, Ci, Cip, Cop);
   O2M_LAUNCH_CHECK();
   const int pb = (Ci + NT - 1) / NT;
-  hipLaunchKernelGGL(style_bwd_batch_kernel, dim3(pb + B + (d ? Cop : 0)), dim3(NT), 0, st, gs, w, e, s, Ws, gWs, gbs,
+  hipLaunchKernelGGL(style_bwd_batch_kernel, dim3(pb + B + (d ? (Cop + 7) / 8 : 0)), dim3(NT), 0, st, gs, w, e, s, Ws, gWs, gbs,
                      gw, d ? gq : nullptr, B, WD, Ci, Cip, Cop, cs, pb, accumulate);
   O2M_LAUNCH_CHECK();
   return 0;
