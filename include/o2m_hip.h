@@ -151,6 +151,17 @@ typedef struct {
 #define O2M_STATS_MOMENTS 0
 #define O2M_STATS_DOT 1
 int o2m_conv2d_fwd(const o2m_conv_desc* d, void* stream);
+/* The border ring of the data gradient of a 3 x 3 conv behind ReflectionPad2d(1) (blocks.py:17-26,45-57: every residual
+ * block of the generator).  d describes the zero-padded data-gradient conv on the CROPPED domain -- x = the gradient of the
+ * conv's output [B][H][W][Ci], w = the flipped filter [Co][3][3][Ci], y = [B][H][W][Co], bf16, pad / pad_mode ignored -- and y
+ * must already hold that conv's result (o2m_conv2d_fwd with pad 1, O2M_PAD_ZERO; same stream).  ADDED to y, with packed
+ * bf16 atomics: full[oy][ox] at y[R(oy - 1)][R(ox - 1)] for the ring oy in {0, H + 1} or ox in {0, W + 1} of the full
+ * correlation on the padded (H + 2) x (W + 2) domain, R(-1) = 1, R(H) = H - 2: the adjoint of the pad applied to what the
+ * cropped conv leaves out.  Together the two launches equal o2m_conv2d_fwd on the padded domain (pad 2) + the fold
+ * (o2m_conv_desc.fold_pad / o2m_fold_scale_dot), without the 6 % more GEMM rows, the tail launch they cost the
+ * 256 x 256-tile kernel, the zero-fill launch and the fold pass over a 66 x 66 map.  Run-to-run differences in the last
+ * bit of the ring's targets (atomics): not for the deterministic mode.  Ci % 64 == 0 (or 32), Co % 64 == 0, H, W >= 4. */
+int o2m_conv2d_reflect_border(const o2m_conv_desc* d, void* stream);
 /* Rows per InstanceNorm partial for this problem (the tile configuration o2m_conv2d_fwd would select),
  * or 0 when the epilogue cannot emit them (Ho*Wo not a multiple of the tile's row block: the odd-sized
  * discriminator maps -- the caller then runs o2m_instnorm_stats).  d->stats itself is not read. */
@@ -435,6 +446,17 @@ int o2m_pack_nchw(const float* src, void* dst, int32_t B, int32_t C, int32_t H, 
 int o2m_unpack_nhwc(const void* src, float* dst, int32_t B, int32_t C, int32_t H, int32_t W,
                     int32_t Cp, int32_t dtype, void* stream);
 
+/* Adversarial (LSGAN) loss of the discriminator's patch map and the reference's confidence (training.py:111-118,202:
+ * ((D(real) - 1)^2).mean(), (D(fake)^2).mean(), sign(2 D(x) - 1).mean()) in ONE launch; replaces F.mse_loss + the
+ * sign / mean chain (eleven elementwise launches per discriminator step).  scores: internal [N][P][C] (`dtype`), channel
+ * 0 = the logical score.  out (4 floats): out[0] = sum over samples [0, n_first) of (s - t0)^2, out[1] = the same over
+ * [n_first, N) with t1, out[2] / out[3] = sum of sign(2 s - 1) over the two halves (fixed summation order).
+ * o2m_lsgan_bwd: g_scores[n][p][0] = coef[half] * 2 * (s - t_half) with coef a DEVICE pointer to two floats (the upstream
+ * gradients of out[0], out[1]); channels 1.. of g_scores are zeroed. */
+int o2m_lsgan_fwd(const void* scores, float* out, int32_t N, int32_t P, int32_t C, int32_t n_first, float t0, float t1,
+                  int32_t dtype, void* stream);
+int o2m_lsgan_bwd(const void* scores, const float* coef, void* g_scores, int32_t N, int32_t P, int32_t C, int32_t n_first,
+                  float t0, float t1, int32_t dtype, void* stream);
 /* ------------------------------------------------------------------------------------
  * Loss reductions (F.l1_loss / F.mse_loss at training.py:111-112,178,188,202;
  * kl_loss_func loss.py:82-92; path_loss_func loss.py:98-111).  All write per-block fp32

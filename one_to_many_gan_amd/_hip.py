@@ -70,6 +70,7 @@ SIGNATURES = {
     "o2m_launch_timing_read": (_i32, [_vp, _i32]),
     "o2m_debug_fill_blocks": (_i32, [_i32]),
     "o2m_conv2d_fwd": (_i32, [C.POINTER(ConvDesc), _vp]),
+    "o2m_conv2d_reflect_border": (_i32, [C.POINTER(ConvDesc), _vp]),
     "o2m_conv2d_stats_rows": (_i32, [C.POINTER(ConvDesc)]),
     "o2m_conv2d_dots_finalize": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "o2m_amax": (_i32, [_vp, _vp, _i64, _i32, _vp]),
@@ -103,6 +104,8 @@ SIGNATURES = {
     "o2m_gather_images": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "o2m_pack_nchw": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "o2m_unpack_nhwc": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "o2m_lsgan_fwd": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _vp]),
+    "o2m_lsgan_bwd": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _vp]),
     "o2m_reduce_blocks": (_i32, [_i64]),
     "o2m_reduce_fwd": (_i32, [_vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp]),
     "o2m_reduce_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp]),
@@ -222,6 +225,20 @@ def conv2d_fwd(x, w, y, *, in_scale=None, out_scale=None, bias=None, residual=No
     and every output pixel of the padded domain is added at its mirror image (o2m_conv_desc.fold_pad)."""
     return ops().conv2d_fwd(x, w, y, in_scale, out_scale, bias, residual, pad, pad_mode, act, per_sample_w, stride,
                             stats, deq, aux, aux_scaled, fold_pad)
+
+
+def conv2d_reflect_border(x, w, y):
+    """Adds the border ring of the data gradient of a 3 x 3 conv behind ReflectionPad2d(1) to ``y``, which already
+    holds the zero-padded (pad 1) data-gradient conv of ``x`` with ``w`` (o2m_conv2d_reflect_border)."""
+    ops().conv2d_reflect_border(x, w, y)
+
+
+def lsgan_fwd(scores, out, n_first, t0, t1):
+    ops().lsgan_fwd(scores, out, n_first, float(t0), float(t1))
+
+
+def lsgan_bwd(scores, coef, g_scores, n_first, t0, t1):
+    ops().lsgan_bwd(scores, coef, g_scores, n_first, float(t0), float(t1))
 
 
 def conv2d_dots_finalize(partial, dots, nchunks):

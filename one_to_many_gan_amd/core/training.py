@@ -149,13 +149,10 @@ def _l1(a, b):
     return ops.l1_sum(ops.to_internal(a), ops.to_internal(b)) / a.numel()
 
 
-def _mse_to(scores, target: float):
-    s = scores.float()
-    return F.mse_loss(s, torch.full_like(s, target))
-
-
-def _confidence(scores):
-    return torch.sign(scores.detach().float() * 2 - 1).mean()
+def _gan_loss(scores):
+    """((D(G(x)) - 1)^2).mean() (training.py:202) through the fused patch-map reduction."""
+    sums = ops.lsgan_sums(ops.to_internal(scores), scores.shape[0], 1.0, 1.0)
+    return sums[0] / scores.numel()
 
 
 @contextlib.contextmanager
@@ -191,11 +188,12 @@ def discriminator_step(config, device, discriminator, generator, mapping_network
     # the discriminator is per-sample (InstanceNorm, no batch statistics), so the scores and
     # the gradients are the same, with half the launches and twice the rows per GEMM
     both = discriminator(torch.cat([fake.float(), real.float()], dim=0))
-    fake_scores, real_scores = both[:batch], both[batch:]
-    loss = (_mse_to(real_scores, 1.0) + _mse_to(fake_scores, 0.0)) / 2
-
-    sign_real = _confidence(real_scores)
-    sign_fake = -_confidence(fake_scores)
+    # LSGAN loss of both halves and the two confidences from ONE launch over the 2B patch maps (o2m_lsgan_fwd)
+    sums = ops.lsgan_sums(ops.to_internal(both), batch, 0.0, 1.0)
+    n = both[:batch].numel()
+    loss = ops.weighted_sum((sums[0], sums[1]), (0.5 / n, 0.5 / n))
+    conf = sums.detach()
+    sign_fake, sign_real = conf[2] * (-1.0 / n), conf[3] * (1.0 / n)
     ada_p.update_p(sign_real)
 
     loss.backward()
@@ -225,7 +223,7 @@ def _separate_decodes(config, device, generator, discriminator, mapping_network,
     w_trans = mapping_network.get_single_w(batch, blocks, device, 1)
     generated = generator.decode(z_print, w_trans)
     with _frozen(discriminator):
-        gan = _mse_to(discriminator(ada(generated)), 1.0)
+        gan = _gan_loss(discriminator(ada(generated)))
     style = style_cycle_loss_func(w_trans[-1], style_extractor(generated))
     # (device draw when the mapping network draws there too: core/graphed.py)
     theta = torch.rand(batch, device=device) if getattr(mapping_network, "device_draws", False) else torch.rand(batch).to(device)
@@ -299,7 +297,7 @@ def _batched_decodes(config, device, generator, discriminator, mapping_network, 
         with torch.cuda.stream(side):
             style_of_generated = style_extractor(generated)
     with _frozen(discriminator):
-        gan = _mse_to(discriminator(ada(generated)), 1.0)
+        gan = _gan_loss(discriminator(ada(generated)))
 
     if style_of_generated is None:
         style_of_generated = style_extractor(generated)
@@ -355,9 +353,9 @@ def generator_step(config, device, generator, discriminator, mapping_network, st
         rec, idt, gan, style, path = _batched_decodes(config, device, generator, discriminator, mapping_network,
                                                       style_extractor, ada, t_lat, shoeprints, shoemarks, w_mark, mark_ready)
 
-    total = (gan + lam["identity_loss_lambda"] * idt + lam["reconstruction_loss_lambda"] * rec
-             + lam["kl_loss_lambda"] * kl + lam["path_loss_lambda"] * path
-             + lam["style_cycle_loss_lambda"] * style)
+    total = ops.weighted_sum((gan, idt, rec, kl, path, style),
+                             (1.0, lam["identity_loss_lambda"], lam["reconstruction_loss_lambda"], lam["kl_loss_lambda"],
+                              lam["path_loss_lambda"], lam["style_cycle_loss_lambda"]))
     total.backward()
     generator_optimiser.step()
     mapping_network_optimiser.step()

@@ -18,6 +18,9 @@
 // pixels come from a halo patch in LDS (see there).  The result tile D[co][pixel] leaves each lane with consecutive
 // channels of ONE pixel (stem8: the filter rows are permuted for that), i.e. whole 16-B (stem8) / 8-B (fewout)
 // channel vectors per lane: no LDS transpose in the epilogue.
+#include <type_traits>
+#include <utility>
+
 #include "common.h"
 #include "conv_direct.h"
 
@@ -307,6 +310,136 @@ __global__ __launch_bounds__(512, 4) void conv_fewout_kernel(const o2m_conv_desc
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// reflect border (o2m_conv2d_reflect_border): the part of the data gradient of a 3 x 3 conv behind ReflectionPad2d(1)
+// that the zero-padded data-gradient conv on the CROPPED H x W domain leaves out.  With full[oy][ox] the full
+// correlation on the padded (H + 2) x (W + 2) domain, the cropped conv is its interior; the ring oy in {0, H + 1} or
+// ox in {0, W + 1} lands on y[R(oy - 1)][R(ox - 1)], R(-1) = 1, R(H) = H - 2 (the adjoint of the pad).  A ring pixel
+// sees at most three filter taps (one filter row for the top / bottom strips, one filter column for the left / right
+// ones), so the ring is 2 (W + 2) + 2 H pixels x K = 3 Ci per sample: 2 % of the layer's work, against the 6 % more
+// rows + a 128 x 128 tail launch + a zero-fill launch + bf16 atomics on 12 % of the map of the padded-domain form.
+// A block = 64 ring pixels of one strip of one sample (4 pixel tiles = the MFMA's columns) x 64 output channels (filter
+// rows permuted as in stem8 so that a lane ends up with 16 consecutive channels of its pixel); its four waves SPLIT THE
+// REDUCTION (one k-step = 32 channels under one tap; 24 at Ci = 256, six per wave, two in flight) and combine through
+// LDS -- the reduction is a chain of L2 round trips, and the first form (a wave per 64 channels walking all 24 steps on
+// ~6 waves per CU) took 65 us per launch for 5 GFLOP.  Both operands straight from global memory (the three filter taps
+// are L2 resident); results ADDED with packed bf16 atomics (y already holds the cropped conv).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_reflect_border_kernel(const o2m_conv_desc d, const int segs) {
+  constexpr int PT = 4;
+  __shared__ f32x4 part[4][4][64];  // [wave][filter-row tile][lane]: one pixel tile's partials at a time
+  const int H = d.H, W = d.W, Ci = d.Ci, Co = d.Co;
+  const int seg = blockIdx.x % segs, st = (blockIdx.x / segs) & 3, b = blockIdx.x / (4 * segs);
+  const int L = st < 2 ? W + 2 : H, x0 = seg << 6;
+  if (x0 >= L) return;  // (block-uniform)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cw = blockIdx.y * 64;  // the block's 64 output channels; its four waves split the REDUCTION (k-steps w, w + 4, ..)
+  const int g = lane >> 4, li = lane & 15;
+  const rsrc_t xr = make_rsrc(d.x, (unsigned)((size_t)d.B * H * W * Ci * 2));
+  const rsrc_t wr = make_rsrc(d.w, (unsigned)((size_t)Co * 9 * Ci * 2));
+
+  // ring pixel -> position on the padded domain, its (<= 3) source pixels, its target.  The three sources are
+  // consecutive pixels (row strips) / rows (column strips): byte offset vbase + t * vstep where bit t of vmask is set
+  // (kept as base + mask, not as a table: indexed by the run-time tap a table goes to scratch)
+  int oy[PT], ox[PT];
+  unsigned vbase[PT], vmask[PT];
+  const unsigned vstep = (unsigned)((st < 2 ? 1 : W) * Ci) * 2u;
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) {
+    const int i = x0 + 16 * pt + li;
+    oy[pt] = st == 0 ? 0 : (st == 1 ? H + 1 : 1 + i);
+    ox[pt] = st < 2 ? i : (st == 2 ? 0 : W + 1);
+    unsigned m = 0;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int ky = st == 0 ? 2 : (st == 1 ? 0 : t), kx = st < 2 ? t : (st == 2 ? 2 : 0);
+      const int iy = oy[pt] + ky - 2, ix = ox[pt] + kx - 2;
+      if (i < L && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) m |= 1u << t;
+    }
+    const int ky0 = st == 0 ? 2 : 0, kx0 = st < 2 ? 0 : (st == 2 ? 2 : 0);
+    vbase[pt] = (unsigned)(((b * H + oy[pt] + ky0 - 2) * W + ox[pt] + kx0 - 2) * Ci + 8 * g) * 2u;  // (tap 0; may lie outside: masked)
+    vmask[pt] = m;
+  }
+  unsigned woff[4];  // filter row of A tile mt, lane row li: channel cw + 16 (li >> 2) + 4 mt + (li & 3)
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) woff[mt] = (unsigned)((cw + 16 * (li >> 2) + 4 * mt + (li & 3)) * 9 * Ci + 8 * g) * 2u;
+
+  f32x4 acc[PT][4];
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) acc[pt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // k-step gs (0 .. 3 nks - 1) = 32 channels ks = gs % nks under tap t = gs / nks; this wave takes gs = wave + 4 j, two
+  // steps in flight.  A step past the end loads through the out-of-range offset (zeros, no traffic).
+  const int nks = Ci >> 5, nstep = 3 * nks;
+  u32x4 a0[4], a1[4], q0[PT], q1[PT];
+  auto load_step = [&](int gs_, u32x4 (&a)[4], u32x4 (&q)[PT]) {
+    const int gs = __builtin_amdgcn_readfirstlane(gs_);
+    const bool live = gs < nstep;
+    const int t = gs / nks, ks = gs - t * nks;
+    const int ky = st == 0 ? 2 : (st == 1 ? 0 : t), kx = st < 2 ? t : (st == 2 ? 2 : 0);
+    const int wso = __builtin_amdgcn_readfirstlane(live ? ((ky * 3 + kx) * Ci + 32 * ks) * 2 : 0);
+    const int xso = __builtin_amdgcn_readfirstlane(live ? 64 * ks : 0);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) a[mt] = __builtin_amdgcn_raw_buffer_load_b128(wr, (int)(live ? woff[mt] : OOB_OFF), wso, 0);
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      const bool ok = live && ((vmask[pt] >> t) & 1u);
+      q[pt] = __builtin_amdgcn_raw_buffer_load_b128(xr, (int)(ok ? vbase[pt] + (unsigned)t * vstep : OOB_OFF), xso, 0);
+    }
+  };
+  auto multiply = [&](const u32x4 (&a)[4], const u32x4 (&q)[PT]) {
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+        acc[pt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(a[mt]), as_frag(q[pt]), acc[pt][mt], 0, 0, 0);
+  };
+  load_step(wave, a0, q0);
+  load_step(wave + 4, a1, q1);
+#pragma unroll 1
+  for (int gs = wave; gs < nstep; gs += 8) {
+    multiply(a0, q0);
+    load_step(gs + 8, a0, q0);
+    multiply(a1, q1);  // (gs + 4 >= nstep: zero fills)
+    load_step(gs + 12, a1, q1);
+  }
+
+  // ---- the four waves' partials meet in LDS, one pixel tile per round; wave pt adds pixel tile pt to y ---------------
+  unsigned short* __restrict__ Y = static_cast<unsigned short*>(d.y);
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) part[wave][mt][lane] = acc[pt][mt];
+    __syncthreads();
+    if (wave == pt && x0 + 16 * pt + li < L) {
+      float o[16];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        f32x4 v = part[0][mt][lane];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {
+          const f32x4 u = part[k][mt][lane];
+          v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[4 * mt + r] = v[r];
+      }
+      int ty = oy[pt] - 1, tx = ox[pt] - 1;
+      ty = ty < 0 ? 1 : (ty >= H ? H - 2 : ty);
+      tx = tx < 0 ? 1 : (tx >= W ? W - 2 : tx);
+      float lo[8], hi[8];
+#pragma unroll
+      for (int qq = 0; qq < 8; ++qq) { lo[qq] = o[qq]; hi[qq] = o[8 + qq]; }
+      unsigned short* dst = Y + ((size_t)(b * H + ty) * W + tx) * Co + cw + 16 * g;
+      atomic_add8(dst, lo);
+      atomic_add8(dst + 8, hi);
+    }
+    __syncthreads();
+  }
+}
+
 bool plain(const o2m_conv_desc& d) {
   return d.dtype == O2M_BF16 && d.stride <= 1 && !d.in_scale && !d.out_scale && !d.residual && !d.aux && !d.aux_scaled &&
          !d.fold_pad && d.w_batch_stride == 0 && !d.deq_scale && d.KH == d.KW;
@@ -381,3 +514,22 @@ int launch_fewout(const o2m_conv_desc& d, hipStream_t s) {
 }
 
 }  // namespace o2m_direct
+
+extern "C" int o2m_conv2d_reflect_border(const o2m_conv_desc* d, void* stream) {
+  if (!d || !d->x || !d->w || !d->y) return O2M_ERR_BAD_ARG;
+  if (d->dtype != O2M_BF16 || d->KH != 3 || d->KW != 3 || d->B <= 0 || d->H < 4 || d->W < 4) return O2M_ERR_BAD_ARG;
+  if (d->Ci <= 0 || d->Co <= 0 || (d->Ci % 64 && d->Ci != 32) || d->Co % 64) return O2M_ERR_BAD_ARG;
+  if (d->in_scale || d->out_scale || d->bias || d->residual || d->stats || d->aux || d->aux_scaled || d->w_batch_stride ||
+      d->stride > 1 || d->fold_pad || d->deq_scale)
+    return O2M_ERR_BAD_ARG;
+  if ((long)d->B * d->H * d->W * d->Ci * 2 > 0x7fffffffL || (long)d->Co * 9 * d->Ci * 2 > 0x7fffffffL) return O2M_ERR_UNSUPPORTED;
+  const int longest = (d->W + 2 > d->H ? d->W + 2 : d->H), segs = (longest + 63) / 64;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  {
+    LaunchScope timed(s, 2.0 * d->B * (2.0 * (d->W + 2) + 2.0 * d->H) * d->Co * 3.0 * d->Ci, "%s", "conv_reflect_border<bf16,3x3>");
+    hipLaunchKernelGGL(conv_reflect_border_kernel, dim3((unsigned)(d->B * 4 * segs), (unsigned)(d->Co / 64)), dim3(256), 0, s,
+                       *d, segs);
+  }
+  O2M_LAUNCH_CHECK();
+  return 0;
+}

@@ -19,6 +19,7 @@
 // in conv_igemm.hip.
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 #include "common.h"
 
 namespace {
@@ -616,81 +617,110 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_p8_kernel(const o2m_wgrad_d
 }
 
 // =============================================================================================
-// Halo-tile weight gradient ("wgrad h3") for the 3 x 3, zero-padded, 64- / 128-channel layers at large maps (the
-// 64 <-> 128 layers at 256 x 256 and the 128 <-> 256 layers at 128 x 128 of the generator: ~40 % of the step's
-// weight-gradient time).  The register-staged tiles above reduce ONE filter tap per block: the input row block is
-// fetched once per tap -- nine L2 -> LDS trips per element, 43-64 FLOP per ingested byte -- and they sit on the
-// L2 -> LDS ingest limit at 0.24-0.33 of the MFMA peak (profiles/r02_c_pmc_wgrad_co64.json).  Here a block owns an
-// 8 x 32 tile of pixels of one sample at a time and a (64 output channels) x (64 input channels) block of the filter
-// for ALL NINE taps:
+// Halo-tile weight gradient ("wgrad halo") for the 3 x 3 and 4 x 4, zero-padded (pad 1), stride-1 layers with 64-channel
+// multiples on both sides that the phase-pipelined kernel above does not take: the 64 <-> 128 layers at 256 x 256 and the
+// 128 <-> 256 layers at 128 x 128 of the generator (~40 % of the step's weight-gradient time) and the 4 x 4 trunk of the
+// discriminator / style extractor on its odd-sized maps (builder.py:269-283).  The register-staged tiles at the top of
+// this file reduce ONE filter tap per block: the input row block is fetched once per tap -- nine (sixteen) L2 -> LDS
+// trips per element, 43-64 FLOP per ingested byte -- and they sit on the L2 -> LDS ingest limit at 0.24-0.33 of the MFMA
+// peak (profiles/r02_c_pmc_wgrad_co64.json).  Here a block owns a TH x 32 tile of OUTPUT pixels of one sample at a time
+// and a (64 output channels) x (64 input channels) block of the filter for ALL taps:
 //   C[co][tap][ci] += sum_{px in tile} G[px][co] * X[px (+) tap][ci]
-// with the G tile (256 px x 128 B) and the 10 x 34 input patch (340 px x 128 B) resident in LDS: every element is
-// ingested once per tile (x: + the 1.33x halo), 250 FLOP per ingested byte.  A k-step = one 32-pixel tile row under
-// one tap; the reduction index (pixels) is the SLOW index of both LDS images (NHWC as in HBM, LDS-DMA fills), so the
-// fragments come out with ds_read_b64_tr_b16 as in the kernels above.  The 8 k-values of a lane are pixels
-// 4 g + 0..3 and 16 + 4 g + 0..3 of the row (the MFMA does not care which pixel is which k as long as both operands
-// agree): a half-wave read then touches 8 CONSECUTIVE pixel rows, and the 16-B chunks of pixel row pp are XOR-swizzled
-// with ((pp >> 1) & 3) << 1 (source side of the DMA) so that those 8 rows' 32-B windows cover all eight 32-B windows
-// of the 256-B bank row, at ANY tap shift.
-//  * 8 waves = 2 (co tile pairs) x 4 (ci tiles of 16): a wave holds 2 x 9 accumulator tiles (72 registers) -- its two G
-//    fragments of a tile row serve all nine taps, one X fragment per tap;
-//  * fully unrolled over the tile's 8 rows and 9 taps: every fragment address is a lane-constant register (one per
-//    tap column and value of (row + ky) & 3: 12 for X, 2 for G) plus an immediate -- no address arithmetic in the loop;
-//  * ONE block per CU with TWO tile buffers (2 x 75 KB of LDS): the fills of tile t + 1 are issued before the MFMAs of
-//    tile t and waited for after them -- one barrier per tile.  (The two-blocks-per-CU form of conv3x3_halo_kernel needs
-//    <= 128 VGPRs; this kernel wants 162 -- 72 accumulators, 14 address registers, fragments in flight -- and spilled.)
-//  * a block walks its slice of the tiles, then stores its 64 x 9 x 64 fp32 partial to its slice's slab;
-//    wgrad_reduce_kernel adds the slices in order (bitwise reproducible).
+// with the G tile (TH x 32 px x 128 B) and the (TH + KS - 1) x (32 + KS - 1) input patch resident in LDS: every element
+// is ingested once per tile (x: + the halo), 250 FLOP per ingested byte.  Tiles are clipped at the map's edge: pixels
+// outside G's map or outside x are out-of-range DMA offsets, i.e. hardware zero fill (no divisibility conditions).
+// A k-step = one 32-pixel tile row under one tap; the reduction index (pixels) is the SLOW index of both LDS images
+// (NHWC as in HBM, LDS-DMA fills), so the fragments come out with ds_read_b64_tr_b16 as in the kernels above.  The 8
+// k-values of a lane are pixels 4 g + 0..3 and 16 + 4 g + 0..3 of the row (the MFMA does not care which pixel is which k
+// as long as both operands agree): a half-wave read then touches 8 CONSECUTIVE pixel rows, and the 16-B chunks of pixel
+// row pp are XOR-swizzled with ((pp >> 1) & 3) << 1 (source side of the DMA) so that those 8 rows' 32-B windows cover
+// all eight 32-B windows of the 256-B bank row, at ANY tap shift.
+//  * 8 waves = 2 (co tile pairs) x 4 (ci tiles of 16): a wave holds 2 x KS^2 accumulator tiles (72 / 128 registers) --
+//    its two G fragments of a tile row serve every tap, one X fragment per tap;
+//  * fully unrolled over the tile's rows and taps: every fragment address is a lane-constant register (one per tap
+//    column and residue of the patch row: the patch pitch PW is 34 / 36 pixels so that there are only 4 / 2 residues)
+//    plus an immediate -- no address arithmetic in the loop.  The reads are INLINE ASM (ds_tr above: no vmcnt(0) drain
+//    behind the fills) in units of one tile row (3 x 3: 9 taps) or half a row (4 x 4: 8 taps), software-pipelined by
+//    one unit: a unit's 20-22 reads are in flight under the previous unit's 16-18 MFMAs;
+//  * ONE block per CU with TWO tile buffers (2 x 75 / 2 x 48 KB of LDS): the fills of tile t + 1 are issued before the
+//    MFMAs of tile t and waited for after them -- one barrier per tile;
+//  * a block walks its slice of the tiles, then stores its 64 x KS^2 x 64 fp32 partial to its slice's slab;
+//    wgrad_reduce_kernel adds the slices in order (bitwise reproducible);
+//  * XS (o2m_wgrad_desc.in_scale, the modulated convs; 3 x 3 only): dW = sum_b s[b, ci] * (per-sample partial).  A lane's
+//    accumulators all belong to ONE input channel (the MFMA's output column = lane & 15), so the style is a per-lane
+//    scalar: the tile loop accumulates the current sample's partial and folds it into the total with 72 FMAs when the
+//    sample changes -- the scaled input x * s is never materialised (the epilogue that wrote it for this kernel's
+//    predecessor moved 0.8 GB per launch at 256 x 256).
+// Measured (round 4, in-step): 1220 TFLOP/s on the 3 x 3 layers (register-staged tiles: 600-820).
 // =============================================================================================
+template <int N, typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl<N>(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
+template <int KS, int TH, int PW, bool XS>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_halo_kernel(const o2m_wgrad_desc d, const int tiles_per_slice) {
-  constexpr int PW = 34, NPIX = 10 * PW, PFILLS = (NPIX + 7) / 8;  // 340 patch pixels, 43 fills of 8
-  constexpr int PATCH_B = PFILLS * 1024, G_B = 256 * 128;           // 44032 + 32768 bytes
-  constexpr int TILE_B = PATCH_B + G_B;                             // one tile buffer
+  static_assert(!XS || KS == 3, "the in-kernel style scale doubles the accumulators: 3 x 3 only");
+  constexpr int NTAP = KS * KS, PCOLS = 32 + KS - 1;
+  constexpr int NPIX = (TH + KS - 1) * PW, PFILLS = (NPIX + 7) / 8;  // patch pixels, fills of 8
+  constexpr int GFILLS = TH * 4;                                      // G tile: TH rows x 32 pixels
+  constexpr int PATCH_B = PFILLS * 1024, G_B = GFILLS * 1024;
+  constexpr int TILE_B = PATCH_B + G_B;                               // one tile buffer
+  constexpr int KYU = KS == 3 ? 3 : 2, UPR = KS / KYU, TPU = KYU * KS;  // filter rows / units per tile row, taps per unit
+  constexpr int NU = TH * UPR;                                        // units per tile
+  constexpr int NV = PW % 8 == 4 ? 2 : (PW % 4 == 2 ? 4 : 8);         // residues of (patch row * PW) & 7
+  static_assert(PW >= PCOLS && NU % 2 == 0, "geometry");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __attribute__((address_space(3))) void lds_void;
-  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
-  const int H = d.H, W = d.W, Ci = d.Ci, Co = d.Co;
-  const int K = 9 * Ci;
+  const int H = d.H, W = d.W, Ci = d.Ci, Co = d.Co, pad = d.pad;
+  const int Ho = H + 2 * pad - KS + 1, Wo = W + 2 * pad - KS + 1;
+  const int K = NTAP * Ci;
   const int nci = Ci >> 6, pairs = (Co >> 6) * nci;
   const int bid = xcd_tile_order(blockIdx.x, gridDim.x);  // the filter blocks of one slice share G and x: one XCD
   const int pair = bid % pairs, slice = bid / pairs;
   const int co0 = (pair / nci) << 6, ci0 = (pair % nci) << 6;
-  const int tiles_x = W >> 5, tpi = tiles_x * (H >> 3), total = d.B * tpi;
+  const int tiles_x = (Wo + 31) >> 5, tpi = tiles_x * ((Ho + TH - 1) / TH), total = d.B * tpi;
   const int t_begin = slice * tiles_per_slice, t_end = min(total, t_begin + tiles_per_slice);
   const rsrc_t xr = make_rsrc(d.x, (unsigned)((size_t)d.B * H * W * Ci * 2));
-  const rsrc_t gr = make_rsrc(d.gy, (unsigned)((size_t)d.B * H * W * Co * 2));
+  const rsrc_t gr = make_rsrc(d.gy, (unsigned)((size_t)d.B * Ho * Wo * Co * 2));
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
 
   // ---- fills: a wave-instruction fills 8 pixels x 128 B; lane l owns slot (l & 7) of pixel 8 f + (l >> 3) and fetches
-  // the chunk the swizzle maps there.  Offsets are recomputed per tile (the kernel must fit 128 VGPRs).
+  // the chunk the swizzle maps there.  Offsets are recomputed per tile.
   auto issue_tile = [&](int t, int buf) {
     const int b = t / tpi, tis = t - b * tpi;
-    const int ty0 = (tis / tiles_x) << 3, tx0 = (tis % tiles_x) << 5;
+    const int ty0 = (tis / tiles_x) * TH, tx0 = (tis % tiles_x) << 5;
     char* patch = smem + buf * TILE_B;
     char* gbuf = patch + PATCH_B;
     int ln = lane;
     asm volatile("" : "+v"(ln));  // keeps the offset arithmetic inside the tile loop
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
+    for (int j = 0; j < (PFILLS + 7) / 8; ++j) {
       const int f = 8 * j + wave;
       if (f >= PFILLS) continue;  // wave-uniform
       const int pp = 8 * f + (ln >> 3);
       const int c = (ln & 7) ^ (((pp >> 1) & 3) << 1);
       const int py = pp / PW, px = pp - py * PW;
-      const int gy = ty0 + py - 1, gx = tx0 + px - 1;
-      const bool ok = pp < NPIX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      const int gy = ty0 + py - pad, gx = tx0 + px - pad;
+      const bool ok = pp < NPIX && px < PCOLS && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
       const unsigned off = ok ? (unsigned)(((b * H + gy) * W + gx) * Ci + ci0 + c * 8) * 2u : OOB_OFF;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void*)(patch + f * 1024), 16, (int)off, 0, 0, 0);
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < (GFILLS + 7) / 8; ++j) {
       const int f = 8 * j + wave;  // tile pixels 8 f .. 8 f + 7: row f >> 2, columns 8 (f & 3) ..
+      if (f >= GFILLS) continue;
       const int pp = 8 * f + (ln >> 3);
       const int c = (ln & 7) ^ (((pp >> 1) & 3) << 1);
-      const unsigned off = (unsigned)(((b * H + ty0 + (pp >> 5)) * W + tx0 + (pp & 31)) * Co + co0 + c * 8) * 2u;
+      const int oy = ty0 + (pp >> 5), ox = tx0 + (pp & 31);
+      const unsigned off = (oy < Ho && ox < Wo) ? (unsigned)(((b * Ho + oy) * Wo + ox) * Co + co0 + c * 8) * 2u : OOB_OFF;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(gr, (lds_void*)(gbuf + f * 1024), 16, (int)off, 0, 0, 0);
     }
   };
@@ -704,79 +734,110 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_halo_kernel(const o2m_wgrad
   // G image: pixel row index 32 r + pg (+ 16): swizzle ((pix >> 1) & 3) is a lane constant
   const int ga0 = PATCH_B + pg * 128 + (((2 * ct0 + (p >> 1)) ^ (((pg >> 1) & 3) << 1)) << 4) + 8 * (p & 1);
   const int ga1 = ga0 ^ 32;  // co tile ct0 + 1: the next 32-B window (ct0 is even)
-  // patch image: pixel (r + ky) * 34 + kx + pg (+ 16); ((pp >> 1) & 3) = ((r + ky) + ((kx + pg) >> 1)) & 3
-  int xa[3][4];
+  // patch image: pixel pr * PW + kx + pg (+ 16), pr = r + ky;  (pp & 7) = ((pr * PW) & 7 + kx + pg) & 7, and
+  // (pr * PW) & 7 takes NV values, selected by pr % NV
+  int xa[KS][NV];
 #pragma unroll
-  for (int kx = 0; kx < 3; ++kx)
+  for (int kx = 0; kx < KS; ++kx)
 #pragma unroll
-    for (int v = 0; v < 4; ++v)
-      xa[kx][v] = (kx + pg) * 128 + (((2 * cit + (p >> 1)) ^ (((v + ((kx + pg) >> 1)) & 3) << 1)) << 4) + 8 * (p & 1);
+    for (int v = 0; v < NV; ++v)
+      xa[kx][v] = (kx + pg) * 128 + (((2 * cit + (p >> 1)) ^ ((((((v * PW) & 7) + kx + pg) >> 1) & 3) << 1)) << 4) + 8 * (p & 1);
 
-  f32x4 acc[2][9];
+  f32x4 acc[2][NTAP];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int t = 0; t < 9; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NTAP; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // XS: `cur` holds the running sample's partial, `acc` the scaled total
+  f32x4 cur[XS ? 2 : 1][XS ? NTAP : 1];
+  if constexpr (XS) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int t = 0; t < NTAP; ++t) cur[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
-  // fragments of one tile row: the two G fragments and the nine shifted X fragments (inline-asm reads: ds_tr above)
-  struct RowFrags { bf16x8 a0, a1, x[9]; };
+  // fragments of one unit: the two G fragments of its tile row and its TPU shifted X fragments (inline-asm reads)
+  struct UnitFrags { bf16x8 a0, a1, x[TPU]; };
   auto join = [](s16x4 lo, s16x4 hi) {
     const s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8, r);
   };
   const unsigned lbase = lds_addr(smem);
-  auto read_row = [&](RowFrags& f, const unsigned tb, auto rc) {  // rc: std::integral_constant row index
-    constexpr int r = decltype(rc)::value;
+  auto read_unit = [&](UnitFrags& f, const unsigned tb, auto uc) {  // uc: std::integral_constant unit index
+    constexpr int U = decltype(uc)::value, r = U / UPR, hf = U % UPR;
     f.a0 = join(ds_tr<r * 4096>(tb + ga0), ds_tr<r * 4096 + 2048>(tb + ga0));
     f.a1 = join(ds_tr<r * 4096>(tb + ga1), ds_tr<r * 4096 + 2048>(tb + ga1));
-    // (the offsets are immediates of the asm: nine spelled-out calls, tap = 3 ky + kx)
-    f.x[0] = join(ds_tr<(r + 0) * PW * 128>(tb + xa[0][(r + 0) & 3]), ds_tr<(r + 0) * PW * 128 + 2048>(tb + xa[0][(r + 0) & 3]));
-    f.x[1] = join(ds_tr<(r + 0) * PW * 128>(tb + xa[1][(r + 0) & 3]), ds_tr<(r + 0) * PW * 128 + 2048>(tb + xa[1][(r + 0) & 3]));
-    f.x[2] = join(ds_tr<(r + 0) * PW * 128>(tb + xa[2][(r + 0) & 3]), ds_tr<(r + 0) * PW * 128 + 2048>(tb + xa[2][(r + 0) & 3]));
-    f.x[3] = join(ds_tr<(r + 1) * PW * 128>(tb + xa[0][(r + 1) & 3]), ds_tr<(r + 1) * PW * 128 + 2048>(tb + xa[0][(r + 1) & 3]));
-    f.x[4] = join(ds_tr<(r + 1) * PW * 128>(tb + xa[1][(r + 1) & 3]), ds_tr<(r + 1) * PW * 128 + 2048>(tb + xa[1][(r + 1) & 3]));
-    f.x[5] = join(ds_tr<(r + 1) * PW * 128>(tb + xa[2][(r + 1) & 3]), ds_tr<(r + 1) * PW * 128 + 2048>(tb + xa[2][(r + 1) & 3]));
-    f.x[6] = join(ds_tr<(r + 2) * PW * 128>(tb + xa[0][(r + 2) & 3]), ds_tr<(r + 2) * PW * 128 + 2048>(tb + xa[0][(r + 2) & 3]));
-    f.x[7] = join(ds_tr<(r + 2) * PW * 128>(tb + xa[1][(r + 2) & 3]), ds_tr<(r + 2) * PW * 128 + 2048>(tb + xa[1][(r + 2) & 3]));
-    f.x[8] = join(ds_tr<(r + 2) * PW * 128>(tb + xa[2][(r + 2) & 3]), ds_tr<(r + 2) * PW * 128 + 2048>(tb + xa[2][(r + 2) & 3]));
+    static_for<TPU>([&](auto jc) {
+      constexpr int jj = decltype(jc)::value, pr = r + hf * KYU + jj / KS, kx = jj % KS;
+      const unsigned a = tb + xa[kx][pr % NV];
+      f.x[jj] = join(ds_tr<pr * PW * 128>(a), ds_tr<pr * PW * 128 + 2048>(a));
+    });
   };
-  auto multiply = [&](const RowFrags& f) {
+  auto multiply = [&](const UnitFrags& f, auto uc) {
+    constexpr int hf = decltype(uc)::value % UPR;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a0, f.x[t], acc[0][t], 0, 0, 0);
-      acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a1, f.x[t], acc[1][t], 0, 0, 0);
+    for (int jj = 0; jj < TPU; ++jj) {
+      const int t = hf * TPU + jj;  // tap = (hf * KYU + jj / KS) * KS + jj % KS
+      if constexpr (XS) {
+        cur[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a0, f.x[jj], cur[0][t], 0, 0, 0);
+        cur[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a1, f.x[jj], cur[1][t], 0, 0, 0);
+      } else {
+        acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a0, f.x[jj], acc[0][t], 0, 0, 0);
+        acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a1, f.x[jj], acc[1][t], 0, 0, 0);
+      }
     }
   };
-  using std::integral_constant;
+  auto fold_sample = [&](int b) {  // acc += s[b, this lane's input channel] * cur;  cur = 0
+    if constexpr (XS) {
+      const float sv = d.in_scale[(size_t)b * Ci + ci0 + 16 * cit + (lane & 15)];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) {
+            acc[i][t][qq] += sv * cur[i][t][qq];
+            cur[i][t][qq] = 0.f;
+          }
+    }
+  };
 
   if (t_begin < t_end) issue_tile(t_begin, 0);
+  int cur_b = t_begin / tpi;
 #pragma unroll 1
   for (int t = t_begin; t < t_end; ++t) {
     const int buf = (t - t_begin) & 1;
+    if constexpr (XS) {
+      const int tb_ = t / tpi;  // (uniform) the tiles of a slice are consecutive: a sample's tiles are contiguous
+      if (tb_ != cur_b) { fold_sample(cur_b); cur_b = tb_; }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's fills of tile t have landed ...
     __syncthreads();                                   // ... everybody's have, and everybody is done with tile t - 1
     if (t + 1 < t_end) issue_tile(t + 1, buf ^ 1);     // into the buffer tile t - 1 was read from
     const unsigned tb = lbase + (unsigned)(buf * TILE_B);
-    // rows software-pipelined by one: the reads of row r + 1 are in flight under the 18 MFMAs of row r
-    RowFrags fa, fb;
-    read_row(fa, tb, integral_constant<int, 0>{});
+    // units software-pipelined by one: the reads of unit u + 1 are in flight under the MFMAs of unit u
+    UnitFrags fa, fb;
+    read_unit(fa, tb, std::integral_constant<int, 0>{});
     lds_reads_done();
-    read_row(fb, tb, integral_constant<int, 1>{}); multiply(fa); lds_reads_done();
-    read_row(fa, tb, integral_constant<int, 2>{}); multiply(fb); lds_reads_done();
-    read_row(fb, tb, integral_constant<int, 3>{}); multiply(fa); lds_reads_done();
-    read_row(fa, tb, integral_constant<int, 4>{}); multiply(fb); lds_reads_done();
-    read_row(fb, tb, integral_constant<int, 5>{}); multiply(fa); lds_reads_done();
-    read_row(fa, tb, integral_constant<int, 6>{}); multiply(fb); lds_reads_done();
-    read_row(fb, tb, integral_constant<int, 7>{}); multiply(fa); lds_reads_done();
-    multiply(fb);
+    static_for<NU / 2>([&](auto hc) {
+      constexpr int u = 2 * decltype(hc)::value;
+      read_unit(fb, tb, std::integral_constant<int, u + 1>{});
+      multiply(fa, std::integral_constant<int, u>{});
+      lds_reads_done();
+      if constexpr (u + 2 < NU) read_unit(fa, tb, std::integral_constant<int, u + 2>{});
+      multiply(fb, std::integral_constant<int, u + 1>{});
+      if constexpr (u + 2 < NU) lds_reads_done();
+    });
   }
+  if (t_begin < t_end) fold_sample(cur_b);
 
   // ---- epilogue: C/D of 16x16x32: column = lane & 15 (ci), row = 4 (lane >> 4) + register (co) ---------------------
   float* __restrict__ slab = d.slabs + (size_t)slice * Co * K;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < NTAP; ++t)
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr)
         slab[(size_t)(co0 + 16 * (ct0 + i) + 4 * g + rr) * K + t * Ci + ci0 + 16 * cit + (lane & 15)] = acc[i][t][rr];
@@ -785,16 +846,18 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_halo_kernel(const o2m_wgrad
 // the layers the halo-tile weight gradient takes; *slices: its slicing of the pixel tiles
 inline bool wgrad_halo_ok(const o2m_wgrad_desc& d, long* slices, long* tiles_per_slice) {
   static const int on = [] { const char* e = getenv("O2M_WGRAD_HALO"); return e ? atoi(e) : 1; }();
-  if (!on || d.dtype != O2M_BF16 || d.KH != 3 || d.KW != 3 || d.pad != 1 || d.pad_mode != O2M_PAD_ZERO || d.stride > 1 ||
-      d.in_scale || d.gy_scale || d.splits > 0 || d.Co % 64 || d.Ci % 64 || d.W % 32 || d.H % 8)
+  if (!on || d.dtype != O2M_BF16 || d.KH != d.KW || (d.KH != 3 && d.KH != 4) || d.pad != 1 || d.pad_mode != O2M_PAD_ZERO ||
+      d.stride > 1 || d.gy_scale || d.splits > 0 || d.Co % 64 || d.Ci % 64 || (d.in_scale && d.KH != 3))
     return false;
-  const long pairs = (long)(d.Co / 64) * (d.Ci / 64), total = (long)d.B * (d.H / 8) * (d.W / 32);
+  const int Ho = d.H + 2 - d.KH + 1, Wo = d.W + 2 - d.KW + 1, th = d.KH == 3 ? 8 : 4;
+  if (Ho < 1 || Wo < 1) return false;
+  const long pairs = (long)(d.Co / 64) * (d.Ci / 64), total = (long)d.B * ((Ho + th - 1) / th) * ((Wo + 31) / 32);
   if (pairs > 64) return false;
   if (total < 64) return false;  // (a few tiles: the register-staged tiles' splitting serves those)
   long s = 256 / pairs;  // one resident block per CU
   if (s < 1) s = 1;
   long per = (total + s - 1) / s;
-  if (per < 8) per = 8;  // at least 8 tiles per block, to amortise its 147 KB partial
+  if (per < 8) per = 8;  // at least 8 tiles per block, to amortise its 64 x KS^2 x 64 fp32 partial
   *tiles_per_slice = per;
   *slices = (total + per - 1) / per;
   return true;
@@ -901,17 +964,25 @@ int launch_wgrad_p8(const o2m_wgrad_desc& d, hipStream_t s, long splits, long ro
 }
 
 int launch_wgrad_halo(const o2m_wgrad_desc& d, hipStream_t s, long slices, long per, size_t* slab_floats) {
-  const int K = 9 * d.Ci;
+  const int K = d.KH * d.KW * d.Ci;
   if (slab_floats) {
     *slab_floats = (size_t)slices * d.Co * K;
     return 0;
   }
-  constexpr int lds = 2 * (43 * 1024 + 256 * 128);  // two tile buffers
   const long pairs = (long)(d.Co / 64) * (d.Ci / 64);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_halo_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  {
-    LaunchScope timed(s, 2.0 * d.B * d.H * d.W * d.Co * K, "%s", "conv_wgrad_halo<bf16,64x9x64>");
-    hipLaunchKernelGGL(conv_wgrad_halo_kernel, dim3((unsigned)(slices * pairs)), dim3(512), lds, s, d, (int)per);
+  const int Ho = d.H + 2 - d.KH + 1, Wo = d.W + 2 - d.KW + 1;
+  auto go = [&](auto kern, int lds, const char* name) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    LaunchScope timed(s, 2.0 * d.B * Ho * Wo * d.Co * K, "%s", name);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(slices * pairs)), dim3(512), lds, s, d, (int)per);
+  };
+  // two tile buffers: patch fills (8 pixels each) + G tile
+  constexpr int lds3 = 2 * (((10 * 34 + 7) / 8) * 1024 + 8 * 4 * 1024), lds4 = 2 * (((7 * 36 + 7) / 8) * 1024 + 4 * 4 * 1024);
+  if (d.KH == 3) {
+    if (d.in_scale) go(conv_wgrad_halo_kernel<3, 8, 34, true>, lds3, "conv_wgrad_halo<bf16,64x9x64>");
+    else go(conv_wgrad_halo_kernel<3, 8, 34, false>, lds3, "conv_wgrad_halo<bf16,64x9x64>");
+  } else {
+    go(conv_wgrad_halo_kernel<4, 4, 36, false>, lds4, "conv_wgrad_halo<bf16,64x16x64>");
   }
   O2M_LAUNCH_CHECK();
   const long n4 = (long)d.Co * K / 4;

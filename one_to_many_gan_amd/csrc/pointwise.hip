@@ -245,6 +245,23 @@ struct GatherTaps {
   const float* wx;
   int W, Hl, Wl;  // width of the fine map; size of the coarse gradient
 };
+// The four tap tables of a launch in LDS (12 KB): a pixel's gather is then table reads from LDS -> four independent
+// coarse loads, instead of a dependent global table load -> address -> data chain per pixel (the gathering passes ran
+// at 1.5-1.9 TB/s of their tensors, profiles/r03_pointwise_bw.txt).  Maps beyond 512 pixels a side keep the global tables.
+constexpr int kTapCap = 512;
+struct TapTables {
+  int sy[kTapCap], sx[kTapCap];
+  float wy[2 * kTapCap], wx[2 * kTapCap];
+};
+__device__ __forceinline__ GatherTaps stage_taps(const GatherTaps& tp, TapTables& t, int H) {
+  if (H > kTapCap || tp.W > kTapCap) return tp;  // (uniform)
+  for (int i = threadIdx.x; i < H; i += blockDim.x) { t.sy[i] = tp.sy[i]; t.wy[2 * i] = tp.wy[2 * i]; t.wy[2 * i + 1] = tp.wy[2 * i + 1]; }
+  for (int i = threadIdx.x; i < tp.W; i += blockDim.x) { t.sx[i] = tp.sx[i]; t.wx[2 * i] = tp.wx[2 * i]; t.wx[2 * i + 1] = tp.wx[2 * i + 1]; }
+  __syncthreads();
+  GatherTaps l = tp;
+  l.sy = t.sy; l.wy = t.wy; l.sx = t.sx; l.wx = t.wx;
+  return l;
+}
 template <typename T, int TG>
 __device__ __forceinline__ void gather_grad(const T* __restrict__ gl, const GatherTaps& tp, int b, int yy, int xx, int C,
                                             int cv, float (&gv)[8]) {
@@ -269,8 +286,10 @@ template <typename T, int MODE, int TG = 0>
 __global__ __launch_bounds__(NT) void in_partial_kernel(const T* __restrict__ x, const T* __restrict__ g,
                                                         const float* __restrict__ mean_rstd,
                                                         float* __restrict__ partial,
-                                                        int P, int C, int act, ChanGeom gm, GatherTaps tp = GatherTaps{}) {
+                                                        int P, int C, int act, ChanGeom gm, GatherTaps tp_in = GatherTaps{}) {
   extern __shared__ float sm[];
+  __shared__ TapTables taps_lds[1];
+  const GatherTaps tp = TG > 0 ? stage_taps(tp_in, taps_lds[0], P / tp_in.W) : tp_in;
   const int b = blockIdx.y, ch = blockIdx.x;
   const int cv = threadIdx.x % gm.CV, pl = threadIdx.x / gm.CV;
   const int pe = min(P, (ch + 1) * gm.chunk);
@@ -377,7 +396,9 @@ __global__ __launch_bounds__(NT) void in_apply_kernel(const T* __restrict__ x, c
                                                       const float* __restrict__ mean_rstd,
                                                       const float* __restrict__ gsums,
                                                       const T* __restrict__ res, T* __restrict__ out,
-                                                      int P, int C, int act, ChanGeom gm, GatherTaps tp = GatherTaps{}) {
+                                                      int P, int C, int act, ChanGeom gm, GatherTaps tp_in = GatherTaps{}) {
+  __shared__ TapTables taps_lds[1];
+  const GatherTaps tp = TG > 0 ? stage_taps(tp_in, taps_lds[0], P / tp_in.W) : tp_in;
   const int b = blockIdx.y, ch = blockIdx.x;
   const int cv = threadIdx.x % gm.CV, pl = threadIdx.x / gm.CV;
   if (pl >= gm.PL) return;
@@ -828,6 +849,51 @@ __global__ __launch_bounds__(NT) void reduce_fwd_kernel(const T* a, const T* b, 
     partials[blockIdx.x] = t0;
     if (mode == O2M_RED_MOM) partials[nblocks + blockIdx.x] = t1;
   }
+}
+
+// ---- adversarial (LSGAN) loss on the discriminator's patch map -----------------------------------------------
+// scores: internal [N][P][C] (C a multiple of 8, channel 0 = the one logical score).  One block: the map is 13-27 k
+// elements.  out[0] / out[1] = sum (s - t)^2 over samples [0, n_first) with target t0 / [n_first, N) with t1;
+// out[2] / out[3] = sum sign(2 s - 1) over the same halves (the reference's confidence, training.py:117-118).
+// Fixed order: a thread's strided walk, then an LDS tree.
+template <typename T>
+__global__ __launch_bounds__(1024) void lsgan_fwd_kernel(const T* __restrict__ s, float* __restrict__ out, int N, int P, int C,
+                                                         int n_first, float t0, float t1) {
+  __shared__ float red[4][1024];
+  float a[4] = {0.f, 0.f, 0.f, 0.f};
+  const long first = (long)n_first * P, total = (long)N * P;
+  for (long i = threadIdx.x; i < total; i += 1024) {
+    const float v = Elem<T>::ld(s + i * C);
+    const int h = i >= first;
+    const float dlt = v - (h ? t1 : t0), u = 2.f * v - 1.f;
+    a[h] += dlt * dlt;
+    a[2 + h] += u > 0.f ? 1.f : (u < 0.f ? -1.f : 0.f);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) red[k][threadIdx.x] = a[k];
+  __syncthreads();
+  for (int w = 512; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + w];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 4) out[threadIdx.x] = red[threadIdx.x][0];
+}
+
+// gs[n][p][0] = coef[half] * 2 (s - t_half), the padded channels 0
+template <typename T>
+__global__ __launch_bounds__(NT) void lsgan_bwd_kernel(const T* __restrict__ s, const float* __restrict__ coef, T* __restrict__ gs,
+                                                       long total, long first, int C, float t0, float t1) {
+  const long i = (long)blockIdx.x * NT + threadIdx.x;
+  if (i >= total) return;
+  const int h = i >= first;
+  const float v = Elem<T>::ld(s + i * C);
+  float o[8] = {coef[h] * 2.f * (v - (h ? t1 : t0)), 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  store8(gs + i * C, o);
+  const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int c = 8; c < C; c += 8) store8(gs + i * C + c, z);
 }
 
 template <typename T>
@@ -1529,6 +1595,26 @@ int o2m_reduce_fwd(const void* a, const void* b, const float* w, float* partials
   DISPATCH_T(dtype, hipLaunchKernelGGL(reduce_fwd_kernel<T>, dim3(nblocks), dim3(NT), 0, s, (const T*)a,
                                        (const T*)b, w, partials, (long)(n_per_sample / 8), nvec, mode,
                                        nblocks));
+  O2M_LAUNCH_CHECK();
+  return 0;
+}
+
+int o2m_lsgan_fwd(const void* scores, float* out, int32_t N, int32_t P, int32_t C, int32_t n_first, float t0, float t1,
+                  int32_t dtype, void* stream) {
+  if (!scores || !out || N <= 0 || P <= 0 || C <= 0 || (C & 7) || n_first < 0 || n_first > N) return O2M_ERR_BAD_ARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(lsgan_fwd_kernel<T>, dim3(1), dim3(1024), 0, s, (const T*)scores, out, N, P, C, n_first, t0, t1));
+  O2M_LAUNCH_CHECK();
+  return 0;
+}
+
+int o2m_lsgan_bwd(const void* scores, const float* coef, void* g_scores, int32_t N, int32_t P, int32_t C, int32_t n_first,
+                  float t0, float t1, int32_t dtype, void* stream) {
+  if (!scores || !coef || !g_scores || N <= 0 || P <= 0 || C <= 0 || (C & 7) || n_first < 0 || n_first > N) return O2M_ERR_BAD_ARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const long total = (long)N * P;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(lsgan_bwd_kernel<T>, dim3((unsigned)((total + NT - 1) / NT)), dim3(NT), 0, s, (const T*)scores,
+                                       coef, (T*)g_scores, total, (long)n_first * P, C, t0, t1));
   O2M_LAUNCH_CHECK();
   return 0;
 }

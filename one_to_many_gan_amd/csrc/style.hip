@@ -123,25 +123,43 @@ __global__ __launch_bounds__(NT) void style_bwd_batch_kernel(const float* gs, co
     return;
   }
   if ((int)blockIdx.x < param_blocks) {
-    const int i = blockIdx.x * NT + threadIdx.x;
-    if (i >= Ci) return;
+    // gWs[i][:] = cs * sum_b gs[b][i] * w[b][:], gbs[i] = sum_b gs[b][i]: 32 input channels x 8 slices of the batch per
+    // block, the slice sums added in slice order.  (One thread per channel walking the whole batch with a run-time
+    // inner loop over WD was a chain of B x WD dependent scalar loads: ~30 us on the launch's critical path.)
+    __shared__ float pr[8][32][MAXWD + 1];
+    const int il = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + il;
     float acc[MAXWD], sb = 0.f;
 #pragma unroll
     for (int j = 0; j < MAXWD; ++j) acc[j] = 0.f;
-    for (int b = 0; b < B; ++b) {
-      const float g = gs[(size_t)b * Cip + i];
-      sb += g;
-      for (int j = 0; j < WD; ++j) acc[j] += g * w[(size_t)b * WD + j];
+    if (i < Ci) {
+      for (int b = sl; b < B; b += 8) {
+        const float gv = gs[(size_t)b * Cip + i];
+        sb += gv;
+#pragma unroll
+        for (int j = 0; j < MAXWD; ++j)
+          if (j < WD) acc[j] += gv * w[(size_t)b * WD + j];
+      }
     }
-    // accumulate = 1 adds into the caller's buffers (the parameters' .grad).  One writer per element WITHIN a
-    // launch; fp32 atomics because two launches for the same layer may run at the same time on two streams (the
-    // decode and the extraction group of generator_step, core/training.py)
-    if (accumulate) {
-      atomicAdd(gbs + i, sb);
-      for (int j = 0; j < WD; ++j) atomicAdd(gWs + (size_t)i * WD + j, acc[j] * cs);
-    } else {
-      gbs[i] = sb;
-      for (int j = 0; j < WD; ++j) gWs[(size_t)i * WD + j] = acc[j] * cs;
+#pragma unroll
+    for (int j = 0; j < MAXWD; ++j) pr[sl][il][j] = acc[j];
+    pr[sl][il][MAXWD] = sb;
+    __syncthreads();
+    // thread (il, j = sl .. step 8): one output element each
+    if (i < Ci) {
+      for (int j = sl; j <= WD; j += 8) {
+        const int jj = j == WD ? MAXWD : j;  // slot MAXWD = the bias sum
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += pr[k][il][jj];
+        // accumulate = 1 adds into the caller's buffers (the parameters' .grad).  One writer per element WITHIN a
+        // launch; fp32 atomics because two launches for the same layer may run at the same time on two streams (the
+        // decode and the extraction group of generator_step, core/training.py)
+        float* dst = j == WD ? gbs + i : gWs + (size_t)i * WD + j;
+        const float v = j == WD ? t : t * cs;
+        if (accumulate) atomicAdd(dst, v);
+        else *dst = v;
+      }
     }
     return;
   }
@@ -214,7 +232,7 @@ int o2m_style_bwd(const float* sums, const float* bias, const float* dots, const
   hipLaunchKernelGGL(style_bwd_sample_kernel, dim3(B, (Cip + 63) / 64), dim3(NT), lds, st, sums, bias, dots, s, d,
                      Q, e, gs, Ci, Cip, Cop);
   O2M_LAUNCH_CHECK();
-  const int pb = (Ci + NT - 1) / NT;
+  const int pb = (Ci + 31) / 32;
   hipLaunchKernelGGL(style_bwd_batch_kernel, dim3(pb + B + (d ? (Cop + 7) / 8 : 0)), dim3(NT), 0, st, gs, w, e, s, Ws, gWs, gbs,
                      gw, d ? gq : nullptr, B, WD, Ci, Cip, Cop, cs, pb, accumulate);
   O2M_LAUNCH_CHECK();

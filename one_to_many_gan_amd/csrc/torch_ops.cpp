@@ -156,6 +156,41 @@ void conv2d_fwd(const Tensor& x, const Tensor& w, Tensor& y, const OptT& in_scal
   O2M_CALL(op, x, o2m_conv2d_fwd(&d, stream));
 }
 
+void conv2d_reflect_border(const Tensor& x, const Tensor& w, Tensor& y) {
+  const char* op = "o2m::conv2d_reflect_border";
+  chk(x, op, "x"); chk(w, op, "w"); chk(y, op, "y");
+  TORCH_CHECK(x.dim() == 4 && y.dim() == 4 && w.dim() == 4, op, ": x, y are NHWC; w is [Co][3][3][Ci]");
+  same_dtype(x, w, op, "x", "w"); same_dtype(x, y, op, "x", "y");
+  TORCH_CHECK(w.size(1) == 3 && w.size(2) == 3 && w.size(3) == x.size(3), op, ": w must be [Co][3][3][Ci] with x's channel count");
+  TORCH_CHECK(y.size(0) == x.size(0) && y.size(1) == x.size(1) && y.size(2) == x.size(2) && y.size(3) == w.size(0), op,
+              ": y must be [B][H][W][Co] on x's map");
+  o2m_conv_desc d{};
+  d.x = ptr(x); d.w = ptr(w); d.y = ptr(y);
+  d.B = i32(x.size(0), op); d.H = i32(x.size(1), op); d.W = i32(x.size(2), op); d.Ci = i32(x.size(3), op);
+  d.Co = i32(w.size(0), op); d.KH = 3; d.KW = 3; d.pad = 1; d.pad_mode = O2M_PAD_ZERO; d.dtype = dtype_code(x, op);
+  O2M_CALL(op, x, o2m_conv2d_reflect_border(&d, stream));
+}
+
+void lsgan_fwd(const Tensor& scores, Tensor& out, int64_t n_first, double t0, double t1) {
+  const char* op = "o2m::lsgan_fwd";
+  chk(scores, op, "scores"); chk_f32(out, op, "out");
+  TORCH_CHECK(scores.dim() == 4 && out.numel() >= 4, op, ": scores is internal [N][H][W][C]; out holds 4 floats");
+  O2M_CALL(op, scores, o2m_lsgan_fwd(ptr(scores), ptr<float>(out), i32(scores.size(0), op), i32(scores.size(1) * scores.size(2), op),
+                                    i32(scores.size(3), op), i32(n_first, op), static_cast<float>(t0), static_cast<float>(t1),
+                                    dtype_code(scores, op), stream));
+}
+
+void lsgan_bwd(const Tensor& scores, const Tensor& coef, Tensor& g_scores, int64_t n_first, double t0, double t1) {
+  const char* op = "o2m::lsgan_bwd";
+  chk(scores, op, "scores"); chk_f32(coef, op, "coef"); chk(g_scores, op, "g_scores");
+  TORCH_CHECK(scores.dim() == 4 && g_scores.sizes() == scores.sizes() && coef.numel() >= 2, op,
+              ": scores / g_scores are internal [N][H][W][C]; coef holds 2 floats");
+  same_dtype(scores, g_scores, op, "scores", "g_scores");
+  O2M_CALL(op, scores, o2m_lsgan_bwd(ptr(scores), ptr<float>(coef), ptr(g_scores), i32(scores.size(0), op),
+                                    i32(scores.size(1) * scores.size(2), op), i32(scores.size(3), op), i32(n_first, op),
+                                    static_cast<float>(t0), static_cast<float>(t1), dtype_code(scores, op), stream));
+}
+
 void conv2d_dots_finalize(const Tensor& partial, Tensor& dots, int64_t nchunks) {
   const char* op = "o2m::conv2d_dots_finalize";
   chk_f32(partial, op, "partial"); chk_f32(dots, op, "dots");
@@ -609,6 +644,9 @@ TORCH_LIBRARY(o2m, m) {
   m.def("conv2d_fwd(Tensor x, Tensor w, Tensor(a!) y, Tensor? in_scale, Tensor? out_scale, Tensor? bias, Tensor? residual, "
         "int pad, int pad_mode, int act, bool per_sample_w, int stride, Tensor(b!)? stats=None, Tensor? deq=None, Tensor? aux=None, "
         "Tensor(c!)? aux_scaled=None, int fold_pad=0) -> ()");
+  m.def("conv2d_reflect_border(Tensor x, Tensor w, Tensor(a!) y) -> ()");
+  m.def("lsgan_fwd(Tensor scores, Tensor(a!) out, int n_first, float t0, float t1) -> ()");
+  m.def("lsgan_bwd(Tensor scores, Tensor coef, Tensor(a!) g_scores, int n_first, float t0, float t1) -> ()");
   m.def("conv2d_dots_finalize(Tensor partial, Tensor(a!) dots, int nchunks) -> ()");
   m.def("amax(Tensor x, Tensor(a!) amax) -> ()");
   m.def("quantize_fp8(Tensor x, Tensor amax, Tensor(a!) y, Tensor(b!) deq) -> ()");
@@ -671,6 +709,9 @@ TORCH_LIBRARY(o2m, m) {
   m.impl("instnorm_finalize", &instnorm_finalize); \
   m.impl("conv2d_stats_rows", &conv2d_stats_rows); \
   m.impl("conv2d_dots_finalize", &conv2d_dots_finalize); \
+  m.impl("lsgan_fwd", &lsgan_fwd);                \
+  m.impl("lsgan_bwd", &lsgan_bwd);                \
+  m.impl("conv2d_reflect_border", &conv2d_reflect_border); \
   m.impl("instnorm_apply", &instnorm_apply);      \
   m.impl("instnorm_bwd", &instnorm_bwd);          \
   m.impl("instnorm_act_resample2d", &instnorm_act_resample2d); \

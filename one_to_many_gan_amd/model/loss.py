@@ -86,7 +86,7 @@ def path_loss_halves(features, cent_fin_diff_h: torch.Tensor) -> torch.Tensor:
     w(theta - h/2) (core/training.py).  Same value as path_loss_func(first halves, second halves, h) (reference
     loss.py:98-111); padded channels are zero in both halves and do not count in the mean."""
     inv_h2 = (1.0 / (cent_fin_diff_h.float() ** 2)).contiguous()
-    total = torch.zeros((), device=features[0][0].device)
+    terms, coefs = [], []
     for entry in features:
         if len(entry) == 3:  # (pair term taken while the map passed, channels, shape): Generator._decode(tap=...)
             term, c, (b2, hh, ww, _) = entry
@@ -94,5 +94,6 @@ def path_loss_halves(features, cent_fin_diff_h: torch.Tensor) -> torch.Tensor:
             t, c = entry
             b2, hh, ww, _ = t.shape
             term = ops.halves_sq_sum(t, inv_h2)
-        total = total + term / (b2 // 2 * c * hh * ww)
-    return total / len(features)
+        terms.append(term)
+        coefs.append(1.0 / ((b2 // 2 * c * hh * ww) * len(features)))
+    return ops.weighted_sum(terms, coefs)  # mean over the maps of each map's mean (loss.py:104-109)

@@ -581,6 +581,32 @@ def _pad_cols(t: torch.Tensor, n: int) -> torch.Tensor:
 # kernel scales x while staging it instead (no tensor write; measured: +35 % kernel time and 16 more VGPRs, which
 # keep small kernels of the main stream from sharing its CUs -- kept for A/B).
 _WGRAD_XS = _os.environ.get("O2M_WGRAD_INSCALE", "0") != "1"
+_WGRAD_HALO = _os.environ.get("O2M_WGRAD_HALO", "1") != "0" and _os.environ.get("O2M_WGRAD_ATOMICS", "0") != "1"
+
+
+# O2M_BORDER_DGRAD=1 (experiment, off): the data gradient of a conv behind ReflectionPad2d(1) as the zero-padded conv on
+# the CROPPED domain (a whole number of 256-row tiles per sample at 64 x 64: no 6 % more rows, no tail launch, no fold)
+# + o2m_conv2d_reflect_border for the ring the crop leaves out.  Same-box A/B (gpurun_out/r04f/ab.log, r04g): the tail
+# launches shrink by 0.86 ms per step and the border launches cost 1.43 (22 x 65 us, latency-bound): +0.5 ms.  Default:
+# the padded 66 x 66 domain + fold (rounds 1-3).
+_BORDER_DGRAD = _os.environ.get("O2M_BORDER_DGRAD", "0") == "1"
+
+
+def _border_dgrad_ok(prep, g, Hh, Ww, pad, pad_mode) -> bool:
+    return (_BORDER_DGRAD and pad_mode == H.PAD_REFLECT and pad == 1 and prep.kh == 3 and prep.kw == 3
+            and g.dtype == torch.bfloat16 and not deterministic() and prep.cop % 64 == 0 and prep.cip % 64 == 0
+            and min(Hh, Ww) >= 4)
+
+
+def _wgrad_scales_in_kernel(prep, x, pad, pad_mode) -> bool:
+    """Whether the weight gradient of this modulated conv will run on the halo-tile kernel (conv_wgrad.hip:
+    3 x 3, zero padding 1, 64-channel multiples, rows of a multiple of 32 pixels, >= 64 tiles, bf16), which folds the
+    style into its per-sample partials: the scaled input x * s is then not needed at all.  Mirrors wgrad_halo_ok; a
+    mismatch only costs speed (o2m_conv2d_wgrad takes in_scale on every path)."""
+    B, Hh, Ww, cip = x.shape
+    return (_WGRAD_HALO and x.dtype == torch.bfloat16 and prep.kh == 3 and prep.kw == 3 and pad == 1 and pad_mode == H.PAD_ZERO
+            and prep.cop % 64 == 0 and cip % 64 == 0 and Ww % 32 == 0 and Hh % 8 == 0 and B * (Hh // 8) * (Ww // 32) >= 64
+            and (prep.cop // 64) * (cip // 64) <= 64)
 # O2M_FUSED_DGRAD_DOT=0: zero-padded modulated convs run fold_scale_dot behind their data gradient (round-2 form)
 # instead of taking the style scale and the style dot out of the data-gradient epilogue (O2M_STATS_DOT)
 _FUSED_DGRAD_DOT = _os.environ.get("O2M_FUSED_DGRAD_DOT", "1") == "1"
@@ -814,12 +840,19 @@ class _ConvFn(torch.autograd.Function):
                 nchunks = hp * wp // dot_rows
                 part = torch.empty(B * nchunks * cip * 2, dtype=torch.float32, device=dev)
                 g_x = torch.empty_like(x)
-                if need_w and _WGRAD_XS:
+                if need_w and _WGRAD_XS and not _wgrad_scales_in_kernel(prep, x, pad, pad_mode):
                     xs = torch.empty_like(x)  # x * s for the weight gradient, written while x is in registers
                 H.conv2d_fwd(gu, w_d, g_x, out_scale=s, pad=kpad, pad_mode=H.PAD_ZERO, act=H.ACT_NONE,
                              stats=part, aux=x, aux_scaled=xs)
                 dots = torch.empty((B, cip), dtype=torch.float32, device=dev)
                 H.conv2d_dots_finalize(part, dots, nchunks)
+            elif s is None and _border_dgrad_ok(prep, g, Hh, Ww, pad, pad_mode) and not prep.fp8_ok(True, B * hp * wp):
+                # plain 3 x 3 conv behind ReflectionPad2d(1) (the encoder's residual blocks): cropped-domain conv (the
+                # block's residual gradient added by its epilogue) + the border ring
+                g_x = torch.empty_like(x)
+                H.conv2d_fwd(gu, w_d, g_x, pad=1, pad_mode=H.PAD_ZERO, act=H.ACT_NONE, residual=res_in)
+                H.conv2d_reflect_border(gu, w_d, g_x)
+                res_in = None
             elif (_FOLD_EPILOGUE and s is None and pad_mode == H.PAD_REFLECT and pad == 1 and g.dtype == torch.bfloat16
                   and not deterministic() and not prep.fp8_ok(True, B * hp * wp)
                   and min(Hh, Ww) >= 2 * pad + 2):
@@ -832,8 +865,18 @@ class _ConvFn(torch.autograd.Function):
                 H.conv2d_fwd(gu, w_d, g_x, pad=kpad, pad_mode=H.PAD_ZERO, act=H.ACT_NONE, residual=res_in, fold_pad=pad)
                 res_in = None
             else:
-                gxp = torch.empty((B, hp, wp, cip), dtype=g.dtype, device=dev)
-                if prep.fp8_ok(True, B * hp * wp):  # e5m2 gradients x e4m3 filter
+                fold = pad if pad_mode == H.PAD_REFLECT else 0  # what the pass behind the GEMM still has to fold
+                border = s is not None and _border_dgrad_ok(prep, g, Hh, Ww, pad, pad_mode) and not prep.fp8_ok(True, B * hp * wp)
+                if border:  # modulated conv behind ReflectionPad2d(1): cropped-domain conv + border ring, nothing left to fold
+                    gxp = torch.empty((B, Hh, Ww, cip), dtype=g.dtype, device=dev)
+                    H.conv2d_fwd(gu, w_d, gxp, pad=1, pad_mode=H.PAD_ZERO, act=H.ACT_NONE)
+                    H.conv2d_reflect_border(gu, w_d, gxp)
+                    fold = 0
+                else:
+                    gxp = torch.empty((B, hp, wp, cip), dtype=g.dtype, device=dev)
+                if border:
+                    pass
+                elif prep.fp8_ok(True, B * hp * wp):  # e5m2 gradients x e4m3 filter
                     w8, rec = prep.get_fp8(True)
                     H.conv2d_fwd(_quantize(gu, torch.float8_e5m2, rec[0:2]), w8, gxp, pad=kpad, pad_mode=H.PAD_ZERO,
                                  act=H.ACT_NONE, deq=rec)
@@ -856,10 +899,9 @@ class _ConvFn(torch.autograd.Function):
                             xs = torch.empty_like(x)  # written by the head's fused kernel
                     else:
                         g_x = torch.empty_like(x)
-                        if s is not None and need_w and _WGRAD_XS:
+                        if s is not None and need_w and _WGRAD_XS and not _wgrad_scales_in_kernel(prep, x, pad, pad_mode):
                             xs = torch.empty_like(x)  # x * s for the weight gradient, written while x is being read
-                        H.fold_scale_dot(gxp, x if s is not None else None, s, g_x, dots,
-                                         pad if pad_mode == H.PAD_REFLECT else 0, xs=xs, gres=res_in)
+                        H.fold_scale_dot(gxp, x if s is not None else None, s, g_x, dots, fold, xs=xs, gres=res_in)
                         res_in = None
                 else:
                     g_x = gxp
@@ -942,8 +984,7 @@ class _ConvFn(torch.autograd.Function):
                     launch_wgrad()  # x * s has just been written by the head's fused kernel
                 style_and_count()
 
-            link.deferred = {"gxp": gxp, "s": s, "dots": dots, "pad": pad if pad_mode == H.PAD_REFLECT else 0,
-                             "xs": xs, "finish": finish}
+            link.deferred = {"gxp": gxp, "s": s, "dots": dots, "pad": fold, "xs": xs, "finish": finish}
         else:
             style_and_count()
         # (separate names: style_and_count may run later, from the block's first conv, and reads g_tw / g_tb)
@@ -1367,6 +1408,61 @@ class _HalvesTapFn(torch.autograd.Function):
 def halves_sq_tap(t, w):
     """``t`` (to be used in place of the argument from here on) and the pair term of its two batch halves."""
     return _HalvesTapFn.apply(t, w)
+
+
+class _LsganFn(torch.autograd.Function):
+    """[sum (s - t0)^2 over samples [0, n_first), sum (s - t1)^2 over the rest, sum sign(2 s - 1) over each half] of a
+    discriminator patch map (internal [N][h][w][C], channel 0 = the score): the adversarial loss and the confidence of
+    training.py:111-118,202 from one launch (o2m_lsgan_fwd); the confidences carry no gradient."""
+
+    @staticmethod
+    def forward(ctx, scores, n_first, t0, t1):
+        out = torch.empty(4, dtype=torch.float32, device=scores.device)
+        H.lsgan_fwd(scores, out, n_first, t0, t1)
+        ctx.save_for_backward(scores)
+        ctx.args = (n_first, t0, t1)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (scores,) = ctx.saved_tensors
+        gs = torch.empty_like(scores)
+        H.lsgan_bwd(scores, g.contiguous(), gs, *ctx.args)  # (the kernel reads g[0], g[1]; the sign sums are constants)
+        return gs, None, None, None
+
+
+def lsgan_sums(scores, n_first, t0, t1):
+    return _LsganFn.apply(scores, n_first, float(t0), float(t1))
+
+
+_WSUM_COEFS: dict = {}
+
+
+class _WeightedSumFn(torch.autograd.Function):
+    """sum_i c_i * x_i over device scalars with host constants c_i: one stack + one dot forward, one scaling backward
+    -- instead of a mul and an add per term and their mirror images from the autograd engine (the loss arithmetic of
+    training.py:236-243 and loss.py:104-109 was ~60 single-element launches per step)."""
+
+    @staticmethod
+    def forward(ctx, coefs, *xs):
+        ctx.coefs = coefs
+        return torch.dot(torch.stack([x.reshape(()) for x in xs]), coefs)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None, *(g * ctx.coefs).unbind(0))
+
+
+def weighted_sum(xs, cs):
+    """``xs``: fp32 device scalars; ``cs``: Python floats."""
+    dev = xs[0].device
+    key = (dev, tuple(float(c) for c in cs))
+    coefs = _WSUM_COEFS.get(key)
+    if coefs is None:
+        if len(_WSUM_COEFS) > 256:
+            _WSUM_COEFS.clear()
+        coefs = _WSUM_COEFS[key] = torch.tensor(key[1], dtype=torch.float32, device=dev)
+    return _WeightedSumFn.apply(coefs, *[x.float() if x.dtype != torch.float32 else x for x in xs])
 
 
 def l1_sum(a, b):

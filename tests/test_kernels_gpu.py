@@ -566,7 +566,7 @@ def test_launch_timer_files_every_kernel_of_a_call_under_its_own_name():
     assert p8[0] == 1 and tail[0] == 1
     assert p8[2] == 256 * 256 * per_row and tail[2] == (rows - 256 * 256) * per_row
     assert 0 < tail[1] < p8[1] < 1e-3
-    wg = [k for k in stats if k.startswith("conv_wgrad<bf16")]
+    wg = [k for k in stats if k.startswith("conv_wgrad")]  # (whichever weight-gradient kernel the shape selects)
     assert len(wg) == 1 and stats[wg[0]][2] == rows * per_row and stats["wgrad_reduce"][0] == 1
     assert H.launch_timing_read() == {}  # reading clears the records
 
@@ -800,29 +800,74 @@ def test_phase_pipelined_weight_gradient_matches_torch(reflect):
         assert float(per_tap.max()) < 5e-5, per_tap
 
 
+@pytest.mark.parametrize("shape", [(16, 64, 64, 256, 256), (3, 20, 70, 64, 128), (2, 8, 4, 32, 64)], ids=str)
+def test_reflect_border_completes_the_cropped_data_gradient(shape):
+    """o2m_conv2d_reflect_border: the zero-padded data-gradient conv on the cropped domain + the border ring = the
+    adjoint of conv(ReflectionPad2d(1)(x)), i.e. torch's own gradient of that composition in fp32 on the same
+    bf16-valued operands -- at the step's shape (256 -> 256 at 64 x 64: the phase-pipelined kernel with exactly 256 tiles),
+    on a wide ragged map and on the smallest one."""
+    import torch.nn.functional as F
+
+    from one_to_many_gan_amd import _hip as H
+
+    B, Hh, Ww, Cg, Cx = shape  # Cg: channels of the incoming gradient (the conv's outputs), Cx: of the conv's input
+    torch.manual_seed(41)
+    g = torch.randn(B, Hh, Ww, Cg, device="cuda").bfloat16()
+    w = (torch.randn(Cg, Cx, 3, 3, device="cuda") / (9 * Cx) ** 0.5).bfloat16()  # the layer's filter [Co][Ci][3][3]
+    # data-gradient filter: [Ci][ky][kx][Co] flipped (ops.PreparedWeight w_d)
+    w_d = w.flip(2, 3).permute(1, 2, 3, 0).contiguous()
+    gx = torch.empty(B, Hh, Ww, Cx, device="cuda", dtype=torch.bfloat16)
+    H.launch_timing(True)
+    try:
+        H.conv2d_fwd(g, w_d, gx, pad=1, pad_mode=H.PAD_ZERO, act=H.ACT_NONE)
+        H.conv2d_reflect_border(g, w_d, gx)
+        names = set(H.launch_timing_read())
+    finally:
+        H.launch_timing(False)
+    assert "conv_reflect_border<bf16,3x3>" in names, names
+    if shape[0] == 16:
+        assert names == {"conv_igemm_p8<bf16,256x256>", "conv_reflect_border<bf16,3x3>"}, names  # one round, no tail launch
+    x = torch.zeros(B, Cx, Hh, Ww, device="cuda", requires_grad=True)
+    y = F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), w.float())
+    (y * g.float().permute(0, 3, 1, 2)).sum().backward()
+    ref = x.grad.permute(0, 2, 3, 1)
+    err = float((gx.float() - ref).norm() / ref.norm())
+    assert err < 4e-3, err
+    ring = torch.zeros(Hh, Ww, dtype=torch.bool, device="cuda")
+    ring[1], ring[-2], ring[:, 1], ring[:, -2] = True, True, True, True
+    err_ring = float((gx.float() - ref)[:, ring].norm() / ref[:, ring].norm())
+    assert err_ring < 8e-3, err_ring  # (targets of the ring: one rounding per atomic add)
+
+
 HALO_WGRADS = [
-    # B, H, W, Ci, Co                      (conv_wgrad_halo_kernel: 3 x 3, zero pad 1, W % 32 == 0, H % 8 == 0)
-    (2, 256, 256, 128, 64),    # decoder 128 -> 64 at 256 x 256: two filter blocks, 8 tiles per slice
-    (3, 128, 128, 256, 128),   # decoder 256 -> 128 at 128 x 128: eight filter blocks, an uneven last slice
-    (2, 128, 128, 128, 256),   # encoder 128 -> 256
-    (5, 64, 96, 64, 64),       # one filter block, image borders in most tiles, 6 tiles per sample
+    # B, H, W, Ci, Co, k                   (conv_wgrad_halo_kernel: 3 x 3 / 4 x 4, zero pad 1, 64-channel multiples)
+    (2, 256, 256, 128, 64, 3),    # decoder 128 -> 64 at 256 x 256: two filter blocks, 8 tiles per slice
+    (3, 128, 128, 256, 128, 3),   # decoder 256 -> 128 at 128 x 128: eight filter blocks, an uneven last slice
+    (2, 128, 128, 128, 256, 3),   # encoder 128 -> 256
+    (5, 64, 96, 64, 64, 3),       # one filter block, image borders in most tiles, 6 tiles per sample
+    (4, 50, 70, 64, 64, 3),       # tiles clipped on both axes
+    (4, 127, 127, 64, 128, 4),    # D / S trunk (builder.py:272): 4 x 4 taps, 126 x 126 gradient map
+    (4, 63, 63, 128, 256, 4),     # 62 x 62
+    (8, 31, 31, 256, 512, 4),     # 30 x 30: one clipped tile column, 32 filter blocks
 ]
 
 
 @pytest.mark.parametrize("case", HALO_WGRADS, ids=lambda c: "x".join(map(str, c)))
 def test_halo_tile_weight_gradient_matches_torch(case):
-    """conv_wgrad_halo_kernel (all nine taps of a 64 x 64 filter block per workgroup; G tile and input patch resident in
+    """conv_wgrad_halo_kernel (all taps of a 64 x 64 filter block per workgroup; G tile and input patch resident in
     LDS, inline-asm transposing reads, double-buffered tiles, slabs) against torch's fp32 weight gradient of the same
     bf16-valued operands; every tap and 64-channel block individually; bitwise repeatable."""
     import torch.nn.functional as F
 
     from one_to_many_gan_amd import _hip as H
 
-    B, Hh, Ww, Ci, Co = case
+    B, Hh, Ww, Ci, Co, k = case
+    kernel = f"conv_wgrad_halo<bf16,64x{k * k}x64>"
+    ho, wo = Hh + 2 - k + 1, Ww + 2 - k + 1
     torch.manual_seed(31)
     x = torch.randn(B, Hh, Ww, Ci, device="cuda").bfloat16()
-    g = torch.randn(B, Hh, Ww, Co, device="cuda").bfloat16()
-    dw = torch.zeros(Co, 3, 3, Ci, device="cuda")
+    g = torch.randn(B, ho, wo, Co, device="cuda").bfloat16()
+    dw = torch.zeros(Co, k, k, Ci, device="cuda")
     H.launch_timing(True)
     try:
         H.conv2d_wgrad(x, g, dw, pad=1, pad_mode=H.PAD_ZERO)
@@ -830,13 +875,13 @@ def test_halo_tile_weight_gradient_matches_torch(case):
         names = set(H.launch_timing_read())
     finally:
         H.launch_timing(False)
-    assert "conv_wgrad_halo<bf16,64x9x64>" in names, names
+    assert kernel in names, names
     xin = F.pad(x.float().permute(0, 3, 1, 2), (1,) * 4)
-    ref = torch.nn.grad.conv2d_weight(xin, (Co, Ci, 3, 3), g.float().permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+    ref = torch.nn.grad.conv2d_weight(xin, (Co, Ci, k, k), g.float().permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
     err = float((dw - ref).norm() / ref.norm())
     assert err < 2e-5, err
-    blocks = (dw - ref).view(Co // 64, 64, 9, Ci // 64, 64)
-    refb = ref.reshape(Co // 64, 64, 9, Ci // 64, 64)
+    blocks = (dw - ref).view(Co // 64, 64, k * k, Ci // 64, 64)
+    refb = ref.reshape(Co // 64, 64, k * k, Ci // 64, 64)
     per_block = (blocks ** 2).sum(dim=(1, 4)).sqrt() / (refb ** 2).sum(dim=(1, 4)).sqrt()
     assert float(per_block.max()) < 5e-5, per_block
     again = torch.zeros_like(dw)
@@ -845,6 +890,22 @@ def test_halo_tile_weight_gradient_matches_torch(case):
     # accumulates into dw like the other forms (a layer used twice in one backward)
     H.conv2d_wgrad(x, g, again, pad=1, pad_mode=H.PAD_ZERO)
     assert float((again - 2 * ref).norm() / ref.norm()) < 4e-5
+    if k != 3:
+        return
+    # in_scale (the modulated convs): the style folded into the per-sample partials, x * s never materialised
+    sc = torch.rand(B, Ci, device="cuda") * 2 - 0.5
+    dws = torch.zeros_like(dw)
+    H.launch_timing(True)
+    try:
+        H.conv2d_wgrad(x, g, dws, in_scale=sc, pad=1, pad_mode=H.PAD_ZERO)
+        torch.cuda.synchronize()
+        names = set(H.launch_timing_read())
+    finally:
+        H.launch_timing(False)
+    assert kernel in names, names
+    xs = F.pad((x.float() * sc.view(B, 1, 1, Ci)).permute(0, 3, 1, 2), (1,) * 4)
+    refs = torch.nn.grad.conv2d_weight(xs, (Co, Ci, 3, 3), g.float().permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+    assert float((dws - refs).norm() / refs.norm()) < 2e-5
 
 
 def test_tensors_beyond_2_gib_run_as_batch_slices():

@@ -6,7 +6,7 @@
 # defaults are run before every variant, so every variant has its own adjacent baseline.
 pairs=3
 if [ "$1" = "-n" ]; then pairs=$2; shift 2; fi
-run() { env "$@" python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-parity-mode --no-kernel-profile 2>/dev/null |
+run() { env "$@" python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-parity-mode --no-kernel-profile --no-extra-legs 2>/dev/null |
         python -c 'import sys, json; print(json.loads(sys.stdin.read())["ms_per_step"])'; }
 echo -n "warm-up  "; run O2M_AB=warm
 for i in $(seq $pairs); do
