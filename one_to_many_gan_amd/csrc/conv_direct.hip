@@ -319,15 +319,21 @@ __global__ __launch_bounds__(512, 4) void conv_fewout_kernel(const o2m_conv_desc
 // ones), so the ring is 2 (W + 2) + 2 H pixels x K = 3 Ci per sample: 2 % of the layer's work, against the 6 % more
 // rows + a 128 x 128 tail launch + a zero-fill launch + bf16 atomics on 12 % of the map of the padded-domain form.
 // A block = 64 ring pixels of one strip of one sample (4 pixel tiles = the MFMA's columns) x 64 output channels (filter
-// rows permuted as in stem8 so that a lane ends up with 16 consecutive channels of its pixel); its four waves SPLIT THE
-// REDUCTION (one k-step = 32 channels under one tap; 24 at Ci = 256, six per wave, two in flight) and combine through
-// LDS -- the reduction is a chain of L2 round trips, and the first form (a wave per 64 channels walking all 24 steps on
-// ~6 waves per CU) took 65 us per launch for 5 GFLOP.  Both operands straight from global memory (the three filter taps
-// are L2 resident); results ADDED with packed bf16 atomics (y already holds the cropped conv).
+// rows permuted as in stem8 so that a lane ends up with 16 consecutive channels of its pixel); its four waves split the
+// reduction (one k-step = 32 channels under one tap) and combine through LDS as [pixel][channel] rows, added to y as
+// channel PAIRS (packed bf16 atomics in their full-rate shape: two contiguous 128-B segments per wave-instruction).
+// Both operands come straight from global memory.
+// MEASURED (round 4, gpurun_out/r04g, r04h): 65 us per launch at B = 48 (a wave per 64 channels walking all 24 k-steps)
+// -> 54 us (reduction split over the waves) -> 36 us (atomics in the contiguous shape).  What is left is operand
+// traffic: 64 x 64 tiles without LDS sharing move 196 KB per block, 300 MB per launch through L2 for 5 GFLOP.  22
+// launches = 0.8 ms against the 0.9 ms the cropped-domain conv saves the 256 x 256-tile kernel, and the step is 0.5 ms
+// SLOWER with it (three same-box pairs): the step keeps the padded-domain form (ops._BORDER_DGRAD = off).  Making it
+// pay needs the ring as rows of an LDS-tiled GEMM (128 x 128 tiles: 4x less traffic), i.e. a border row mapping in
+// conv_igemm_kernel's loader and fold epilogue -- not built.
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void conv_reflect_border_kernel(const o2m_conv_desc d, const int segs) {
   constexpr int PT = 4;
-  __shared__ f32x4 part[4][4][64];  // [wave][filter-row tile][lane]: one pixel tile's partials at a time
+  __shared__ float part[4][16][64 + 4];  // [wave][pixel][channel]: one pixel tile's partials at a time
   const int H = d.H, W = d.W, Ci = d.Ci, Co = d.Co;
   const int seg = blockIdx.x % segs, st = (blockIdx.x / segs) & 3, b = blockIdx.x / (4 * segs);
   const int L = st < 2 ? W + 2 : H, x0 = seg << 6;
@@ -406,35 +412,38 @@ __global__ __launch_bounds__(256) void conv_reflect_border_kernel(const o2m_conv
     load_step(gs + 12, a1, q1);
   }
 
-  // ---- the four waves' partials meet in LDS, one pixel tile per round; wave pt adds pixel tile pt to y ---------------
+  // ---- the four waves' partials meet in LDS, one pixel tile per round, as [pixel][channel] rows; the 256 threads then
+  // add CHANNEL PAIRS: a wave-instruction covers two pixels x 32 pairs = two contiguous 128-B segments, the full-rate
+  // shape of the memory-side atomics (the lane-per-pixel shape of the accumulators -- 64 scattered dwords per
+  // instruction -- ran the launch at 54 us, MI355X_MICROARCH.md "Global float atomics")
   unsigned short* __restrict__ Y = static_cast<unsigned short*>(d.y);
+  typedef short s16x2_t __attribute__((ext_vector_type(2)));
+  typedef __attribute__((address_space(1))) s16x2_t gs16x2_t;
 #pragma unroll
   for (int pt = 0; pt < PT; ++pt) {
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) part[wave][mt][lane] = acc[pt][mt];
+    for (int mt = 0; mt < 4; ++mt) {
+      const f32x4 v = acc[pt][mt];
+      part[wave][li][16 * g + 4 * mt + 0] = v[0];
+      part[wave][li][16 * g + 4 * mt + 1] = v[1];
+      part[wave][li][16 * g + 4 * mt + 2] = v[2];
+      part[wave][li][16 * g + 4 * mt + 3] = v[3];
+    }
     __syncthreads();
-    if (wave == pt && x0 + 16 * pt + li < L) {
-      float o[16];
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-        f32x4 v = part[0][mt][lane];
+    for (int k = 0; k < 2; ++k) {
+      const int pair = tid + 256 * k, px = pair >> 5, cp = pair & 31;
+      const int i = x0 + 16 * pt + px;
+      if (i < L) {
+        float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-        for (int k = 1; k < 4; ++k) {
-          const f32x4 u = part[k][mt][lane];
-          v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[4 * mt + r] = v[r];
+        for (int wv = 0; wv < 4; ++wv) { s0 += part[wv][px][2 * cp]; s1 += part[wv][px][2 * cp + 1]; }
+        int ty = (st == 0 ? 0 : (st == 1 ? H + 1 : 1 + i)) - 1, tx = (st < 2 ? i : (st == 2 ? 0 : W + 1)) - 1;
+        ty = ty < 0 ? 1 : (ty >= H ? H - 2 : ty);
+        tx = tx < 0 ? 1 : (tx >= W ? W - 2 : tx);
+        unsigned short* dst = Y + ((size_t)(b * H + ty) * W + tx) * Co + cw + 2 * cp;
+        __builtin_amdgcn_global_atomic_fadd_v2bf16((gs16x2_t*)dst, __builtin_bit_cast(s16x2_t, pack_bf2(s0, s1)));
       }
-      int ty = oy[pt] - 1, tx = ox[pt] - 1;
-      ty = ty < 0 ? 1 : (ty >= H ? H - 2 : ty);
-      tx = tx < 0 ? 1 : (tx >= W ? W - 2 : tx);
-      float lo[8], hi[8];
-#pragma unroll
-      for (int qq = 0; qq < 8; ++qq) { lo[qq] = o[qq]; hi[qq] = o[8 + qq]; }
-      unsigned short* dst = Y + ((size_t)(b * H + ty) * W + tx) * Co + cw + 16 * g;
-      atomic_add8(dst, lo);
-      atomic_add8(dst + 8, hi);
     }
     __syncthreads();
   }

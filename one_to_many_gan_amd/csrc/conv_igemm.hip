@@ -1395,6 +1395,11 @@ int launch_cfg(const o2m_conv_desc& d, hipStream_t s, long m_begin = 0, long m_e
 }
 
 
+inline bool f32_big_tiles() {
+  static const bool on = [] { const char* e = getenv("O2M_F32_BIG_TILES"); return e && e[0] == '1'; }();
+  return on;
+}
+
 template <typename T>
 int launch_dtype(const o2m_conv_desc& d, hipStream_t s) {
   if constexpr (sizeof(T) == 2) {
@@ -1428,7 +1433,14 @@ int launch_dtype(const o2m_conv_desc& d, hipStream_t s) {
       }
     }
     if (d.fold_pad) return launch_cfg<T, 128, 128, 2, 2>(d, s);
-    if (tiles_for<256, 256>(d) >= kFillBlocks) return launch_cfg<T, 256, 256, 2, 4>(d, s);
+    if (tiles_for<256, 256>(d) >= kFillBlocks) {
+      // fp32 (bf16x3 split) mode: the 256 x 256 tile spills 8-103 VGPRs (up to 272 B of scratch per lane); 256 x 128 fits
+      // (176-180 VGPRs).  O2M_F32_BIG_TILES=1 keeps the old tile (A/B).
+      if constexpr (sizeof(T) == 4) {
+        if (!f32_big_tiles()) return launch_cfg<T, 256, 128, 4, 2>(d, s);
+      }
+      return launch_cfg<T, 256, 256, 2, 4>(d, s);
+    }
     return launch_cfg<T, 128, 128, 2, 2>(d, s);
   }
   if (d.fold_pad) return launch_cfg<T, 128, 128, 2, 2>(d, s);  // (the one tile compiled with the fold epilogue)
@@ -1456,7 +1468,8 @@ static int stats_rows_for(const o2m_conv_desc& d) {
   if (d.dtype == O2M_BF16 && o2m_direct::stem8_ok(d)) return o2m_direct::stem8_stats_rows(d);  // whole output rows of a block
   if (d.dtype == O2M_BF16 && halo_ok(d)) return 64;  // one partial per wave row of an 8 x 32 tile
   if (d.Co > 128) {
-    if (tiles_for<256, 256>(d) >= kFillBlocks) return 128;  // p8 and the symmetric 256x256 kernel alike
+    if (tiles_for<256, 256>(d) >= kFillBlocks)               // p8 and the symmetric 256x256 kernel alike: 128-row wave rows;
+      return (d.dtype == O2M_F32 && !f32_big_tiles()) ? 64 : 128;  // fp32 mode's 256x128 tile (4 wave rows): 64
     return 64;                                               // 128x128, 2x2 waves
   }
   return 64;  // 256x64 / 256x128 (4 wave rows), 128x128 / 128x64 (2 wave rows), 256x32

@@ -1028,7 +1028,10 @@ int launch_dtype_r2(const o2m_wgrad_desc& d, hipStream_t s, size_t* slab_floats)
   // O2M_WGRAD_TILES=small keeps the 128-wide tiles (A/B measurements)
   static const bool small = [] { const char* e = getenv("O2M_WGRAD_TILES"); return e && e[0] == 's'; }();
   const int K = d.KH * d.KW * d.Ci;
-  if (!small) {
+  // fp32 (bf16x3 split) mode: the 256 x 128 / 128 x 256 register tiles spill 63-199 VGPRs (172-544 B of scratch per lane,
+  // -Rpass-analysis=kernel-resource-usage); the 128 x 128 tile does not.  O2M_F32_BIG_TILES=1 keeps the old selection (A/B).
+  static const bool f32_big = [] { const char* e = getenv("O2M_F32_BIG_TILES"); return e && e[0] == '1'; }();
+  if (!small && (sizeof(T) == 2 || f32_big)) {
     // 128x64 / 64x128 wave tiles (1.5x fewer LDS fragment bytes per MFMA) where they measured
     // faster (tools/sweep_wgrad.py): long reductions for wide layers, K a multiple of 256
     const int st = d.stride > 0 ? d.stride : 1;

@@ -586,9 +586,9 @@ _WGRAD_HALO = _os.environ.get("O2M_WGRAD_HALO", "1") != "0" and _os.environ.get(
 
 # O2M_BORDER_DGRAD=1 (experiment, off): the data gradient of a conv behind ReflectionPad2d(1) as the zero-padded conv on
 # the CROPPED domain (a whole number of 256-row tiles per sample at 64 x 64: no 6 % more rows, no tail launch, no fold)
-# + o2m_conv2d_reflect_border for the ring the crop leaves out.  Same-box A/B (gpurun_out/r04f/ab.log, r04g): the tail
-# launches shrink by 0.86 ms per step and the border launches cost 1.43 (22 x 65 us, latency-bound): +0.5 ms.  Default:
-# the padded 66 x 66 domain + fold (rounds 1-3).
+# + o2m_conv2d_reflect_border for the ring the crop leaves out.  Same-box A/B (gpurun_out/r04f, r04g, r04h): the tail
+# launches shrink by 0.86 ms per step, the border launches cost 1.43 -> 1.18 -> 0.78 ms over three versions of the
+# kernel (L2-traffic-bound: conv_direct.hip) and the step stays 0.5 ms SLOWER.  Default: the padded 66 x 66 domain + fold.
 _BORDER_DGRAD = _os.environ.get("O2M_BORDER_DGRAD", "0") == "1"
 
 

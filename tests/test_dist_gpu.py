@@ -66,3 +66,33 @@ def test_train_loop_under_data_parallelism(tmp_path):
     models = sorted(p.name for p in (tmp_path / "dp" / "models").iterdir())
     assert models == ["1.tar", "2.tar", "3.tar"]
     assert len((tmp_path / "dp" / "log").read_text().splitlines()) == 3
+
+
+@pytest.mark.timeout(600)
+def test_data_parallel_step_equals_the_big_batch_step(tmp_path):
+    """a D+G step on two ranks (local batch 2: early finalisation, the bucket reducers launching inside
+    backward on their comm stream, the group stream, the global-batch KL hook) hands every optimiser the gradient of the
+    single-process batch-4 step on the same four samples -- data parallelism is exact for this step -- to fp32 rounding
+    (parity mode; every random draw tabled by global sample: tests/dp_equiv_worker.py)."""
+    import torch
+
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    worker = os.path.join(ROOT, "tests", "dp_equiv_worker.py")
+    r = subprocess.run([sys.executable, worker, str(tmp_path), "single"], env=env, cwd=ROOT, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29617", worker, str(tmp_path), "dp"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0, r.stderr[-3000:]
+    one = torch.load(tmp_path / "single0.pt", weights_only=True)
+    a, b = (torch.load(tmp_path / f"dp{k}.pt", weights_only=False) for k in (0, 1))
+    for k in ("D", "G", "M", "S"):
+        assert torch.equal(a[k], b[k]), k  # both ranks hold the same reduced gradient
+        ref = one[k]
+        err = float((a[k] - ref).norm() / ref.norm())
+        # fp32-split MFMA products summed over a different partition of the samples (per-rank slabs, then the all-reduce);
+        # ReLU masks are per sample and identical on both sides
+        assert err < 2e-4, (k, err)
+    assert abs(float(a["kl"]) - float(one["kl"])) <= 1e-5 * abs(float(one["kl"]))  # the KL of the GLOBAL batch on each rank
+    assert set(a["launch_logs"]["D"]) == {"hook"} and set(a["launch_logs"]["S"]) == {"hook"}, a["launch_logs"]
