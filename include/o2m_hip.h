@@ -166,6 +166,12 @@ int o2m_conv2d_reflect_border(const o2m_conv_desc* d, void* stream);
  * or 0 when the epilogue cannot emit them (Ho*Wo not a multiple of the tile's row block: the odd-sized
  * discriminator maps -- the caller then runs o2m_instnorm_stats).  d->stats itself is not read. */
 int32_t o2m_conv2d_stats_rows(const o2m_conv_desc* d);
+/* Partial rows PER SAMPLE the epilogue writes to d->stats for this problem: Ho*Wo / o2m_conv2d_stats_rows(d) for the
+ * kernels whose partials cover consecutive pixels, 4 x (8 x 32 tiles per sample, clipped at the map's edge) for the
+ * halo-tile kernel of the 4 x 4 trunk convolutions on their odd-sized maps (each partial then covers the pixels of its
+ * tile's wave row that exist); 0: the epilogue cannot emit them (run o2m_instnorm_stats).  The stats workspace holds
+ * B * chunks * Co * 2 floats; o2m_instnorm_finalize takes `chunks` as its nchunks with P = Ho*Wo. */
+int32_t o2m_conv2d_stats_chunks(const o2m_conv_desc* d);
 /* dots[b][c] = sum over the nchunks = Ho*Wo / R row blocks of sample b of the O2M_STATS_DOT partials
  * (partial [B][nchunks][C][2], even slots), in block order: fixed summation order, no atomics. */
 int o2m_conv2d_dots_finalize(const float* partial, float* dots, int32_t B, int32_t C, int32_t nchunks,

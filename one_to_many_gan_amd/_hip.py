@@ -72,6 +72,7 @@ SIGNATURES = {
     "o2m_conv2d_fwd": (_i32, [C.POINTER(ConvDesc), _vp]),
     "o2m_conv2d_reflect_border": (_i32, [C.POINTER(ConvDesc), _vp]),
     "o2m_conv2d_stats_rows": (_i32, [C.POINTER(ConvDesc)]),
+    "o2m_conv2d_stats_chunks": (_i32, [C.POINTER(ConvDesc)]),
     "o2m_conv2d_dots_finalize": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "o2m_amax": (_i32, [_vp, _vp, _i64, _i32, _vp]),
     "o2m_quantize_fp8": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
@@ -275,6 +276,12 @@ def quantize_fp8(x, y, deq):
     ws = _AMAX_WS.get(x.device, AMAX_PARTIALS)
     ops().amax(x, ws)
     ops().quantize_fp8(x, ws, y, deq)
+
+
+def conv2d_stats_chunks(x, w, y, *, pad, stride=1):
+    """InstanceNorm partial rows per sample the conv's epilogue writes (0: it cannot emit them): the stats workspace is
+    B * chunks * Co * 2 floats and o2m_instnorm_finalize takes ``chunks`` (o2m_conv2d_stats_chunks)."""
+    return ops().conv2d_stats_chunks(x, w, y, pad, stride)
 
 
 def conv2d_stats_rows(x, w, y, *, pad, stride=1):

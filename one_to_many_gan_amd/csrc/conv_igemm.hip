@@ -1338,6 +1338,202 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo_kernel(const o2m_conv_des
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same scheme for KS x KS taps (3 or 4), any zero padding < KS, ANY map size (tiles clipped at the edge: loads outside
+// the image are out-of-range DMA offsets, stores and statistics are masked) and any Co % 64 == 0 (64 output channels per
+// block, blockIdx.y = the channel block): the 4 x 4 trunk of the discriminator / style extractor on its odd-sized maps
+// (255 -> 127 -> 126 -> 63 -> 62 -> 31 -> 30, builder.py:269-283) and its data gradients (pad 2), which ran on the generic
+// 256 x 64 / 128 x 128 tiles at 0.2-0.3 of peak and -- Ho * Wo not being a multiple of any row block -- with a separate
+// InstanceNorm statistics pass.  Here the partial of (tile, wave row) covers whatever pixels of the tile exist:
+// o2m_conv2d_stats_chunks = 4 x tiles per sample rows per sample, summed by o2m_instnorm_finalize as before.
+template <int KS>
+__global__ __launch_bounds__(512, 4) void conv_halo_any_kernel(const o2m_conv_desc d) {
+  using T = unsigned short;
+  constexpr int CO = 64;
+  constexpr int NT = 512, TH = 8, TW = 32, PW = TW + KS - 1, NPIX = (TH + KS - 1) * PW;  // patch pixels
+  constexpr int PFILLS = (NPIX + 7) / 8;                                       // fills of 8 pixels
+  constexpr int PATCH_B = PFILLS * 1024;
+  constexpr int WB = CO * 128;     // one filter tap of one chunk: CO rows x 64 channels
+  constexpr int WFILLS = CO / 8;   // 8 rows per fill
+  constexpr int WPW = WFILLS / 8;  // filter fills per wave (1 or 2)
+  constexpr int NJ = CO / 32;      // 16-column MFMA tiles per wave (wave N = CO / 2)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* patch = smem;
+  char* wbuf = smem + PATCH_B;
+  typedef __attribute__((address_space(3))) void lds_void;
+
+  const int H = d.H, W = d.W, Ci = d.Ci, Co = d.Co, pad = d.pad;
+  const int Ho = H + 2 * pad - KS + 1, Wo = W + 2 * pad - KS + 1;
+  const int K = KS * KS * Ci;
+  const int n0 = blockIdx.y * CO;  // this block's 64 output channels
+  const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH - 1) / TH, tps = tiles_x * tiles_y;
+  const int tile = xcd_tile_order(blockIdx.x, gridDim.x);
+  const int b = tile / tps, tis = tile - b * tps;
+  const int ty0 = (tis / tiles_x) * TH, tx0 = (tis % tiles_x) * TW;
+  const rsrc_t xr = make_rsrc(d.x, (unsigned)((size_t)d.B * H * W * Ci * 2));
+  const rsrc_t wr = make_rsrc(static_cast<const char*>(d.w) + (size_t)b * d.w_batch_stride * 2, (unsigned)((size_t)Co * K * 2));
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // ---- patch fills: fill f = 8 j + wave covers patch pixels 8 f .. 8 f + 7; lane l owns slot (l & 7) of pixel
+  // 8 f + (l >> 3).  The six source offsets are recomputed per chunk (once or twice per block) rather than kept
+  // in registers across the tap loop: the kernel must fit 128 VGPRs for two blocks per CU.
+  auto issue_patch = [&](int cb) {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));  // keeps the offset arithmetic below inside the chunk loop
+#pragma unroll
+    for (int j = 0; j < (PFILLS + 7) / 8; ++j) {
+      const int f = 8 * j + wave;
+      if (f >= PFILLS) continue;  // wave-uniform
+      const int pp = 8 * f + (ln >> 3);
+      const int c = (ln & 7) ^ ((pp >> 1) & 7);
+      const int py = pp / PW, px = pp - py * PW;
+      const int gy = ty0 + py - pad, gx = tx0 + px - pad;
+      const bool ok = pp < NPIX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      const unsigned off = ok ? (unsigned)(((b * H + gy) * W + gx) * Ci + c * 8) * 2u : OOB_OFF;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void*)(patch + f * 1024), 16, (int)off, cb * 2, 0, 0);
+    }
+  };
+  // ---- filter fills: tile_off's swizzle, lane l of the fill of 8-row group q owns linear slot 64 q + l
+  unsigned woff[WPW];
+#pragma unroll
+  for (int j = 0; j < WPW; ++j) {
+    const int q = WPW * wave + j;
+    const int pr = 4 * q + (lane >> 4);
+    const int row = 2 * pr + (((lane & 15) ^ (pr & 15)) >> 3), chk = ((lane & 15) ^ (pr & 15)) & 7;
+    woff[j] = (unsigned)((n0 + row) * K + chk * 8) * 2u;
+  }
+  auto issue_w = [&](int tap, int cb, int buf) {
+#pragma unroll
+    for (int j = 0; j < WPW; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void*)(wbuf + buf * WB + (WPW * wave + j) * 1024), 16, (int)woff[j],
+                                               (tap * Ci + cb) * 2, 0, 0);
+  };
+
+  // ---- fragments -------------------------------------------------------------------------------------
+  // A: lane l holds pixel row (l & 15) of a 16-row tile and reduction elements 8 (l >> 4) + 32 ks .. + 7
+  const int c0 = lane >> 4;
+  // patch pixel of this lane's row at tap (0, 0) in 16-row tile 0; tile i adds (i >> 1) image rows and 16 (i & 1) pixels
+  const int ppb0 = 2 * wm * PW + (lane & 15);
+  // tile_off(R0 + 16 j + r, c) = (tile_off(R0 + r, c) ^ ((j & 1) << 7)) + j * 2048 for R0 % 32 == 0 (as in the p8 kernel)
+  const int fb0 = tile_off(wn * (CO / 2) + (lane & 15), c0);
+
+  f32x4_t acc[4][NJ];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](const int toff, const int buf) {
+    int aoff[4];
+    int pb = ppb0;
+    asm volatile("" : "+v"(pb));  // recompute the four offsets per tap: hoisted, the 36 of them spill to scratch
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int pp = pb + (toff + (i >> 1) * PW + (i & 1) * 16);
+      aoff[i] = (pp << 7) | ((c0 ^ ((pp >> 1) & 7)) << 4);
+    }
+    const char* wb = wbuf + buf * WB;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 a[4], bw[NJ];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8*>(patch + (aoff[i] ^ (ks << 6)));
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) bw[j] = *reinterpret_cast<const bf16x8*>(wb + ((fb0 ^ (((j & 1) << 7) | (ks << 6))) + j * 2048));
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bw[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  // ---- main loop: per 64-channel chunk, the patch once and the nine taps from it ------------------------
+  for (int cb = 0; cb < Ci; cb += 64) {
+    issue_patch(cb);
+    issue_w(0, cb, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int tap = 0; tap < KS * KS; ++tap) {
+      if (tap + 1 < KS * KS) issue_w(tap + 1, cb, (tap + 1) & 1);  // lands while this tap is multiplied
+      compute((tap / KS) * PW + tap % KS, tap & 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();  // next tap's filter has landed; every wave is done with this tap's (and, at the last tap, the patch)
+    }
+  }
+
+  // ---- epilogue -----------------------------------------------------------------------------------------
+  constexpr int CSTR = CO + 4;
+  constexpr int VPR = CO / 8, RPI = NT / VPR;  // 8-channel vectors per row; rows per read-out iteration
+  float* csm = reinterpret_cast<float*>(smem);
+  T* __restrict__ Y = static_cast<T*>(d.y);
+  const T* __restrict__ R = static_cast<const T*>(d.residual);
+  const int act = d.act;
+  const bool stream_out = (size_t)d.B * Ho * Wo * Co * 2 >= ((size_t)64 << 20);
+  const int ec8 = tid % VPR, erow = tid / VPR, en = n0 + ec8 * 8;
+  float esc[8], ebias[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { esc[q] = 1.f; ebias[q] = 0.f; }
+  if (d.out_scale) {
+    const float* sp = d.out_scale + (size_t)b * Co + en;
+    const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 4);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { esc[q] = s0[q]; esc[4 + q] = s1[q]; }
+  }
+  if (d.bias) {
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(d.bias + en), b1 = *reinterpret_cast<const f32x4*>(d.bias + en + 4);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { ebias[q] = b0[q]; ebias[4 + q] = b1[q]; }
+  }
+#pragma unroll 1
+  for (int pass = 0; pass < 4; ++pass) {  // wave row `pass`: tile image rows 2 pass, 2 pass + 1
+    if (wm == pass) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            csm[(i * 16 + 4 * (lane >> 4) + r) * CSTR + wn * (CO / 2) + j * 16 + (lane & 15)] = acc[i][j][r];
+    }
+    lds_barrier();
+    float st[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) st[q] = 0.f;
+#pragma unroll
+    for (int it = 0; it < 64 / RPI; ++it) {
+      const int row = erow + it * RPI;  // 0 .. 63
+      const int gy = ty0 + 2 * pass + (row >> 5), gx = tx0 + (row & 31);
+      if (gy >= Ho || gx >= Wo) continue;  // clipped tile: nothing to store, nothing to count
+      const size_t off = ((size_t)(b * Ho + gy) * Wo + gx) * Co + en;
+      const f32x4 va = *reinterpret_cast<const f32x4*>(csm + row * CSTR + ec8 * 8);
+      const f32x4 vb = *reinterpret_cast<const f32x4*>(csm + row * CSTR + ec8 * 8 + 4);
+      float o[8] = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
+#pragma unroll
+      for (int q = 0; q < 8; ++q) o[q] = o[q] * esc[q] + ebias[q];
+      if (d.stats) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { st[q] += o[q]; st[8 + q] += o[q] * o[q]; }
+      }
+      act_fwd8(o, act);
+      if (R) {
+        float rv[8];
+        load8(R + off, rv);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] += rv[q];
+      }
+      store8x(Y + off, o, stream_out);
+    }
+    // one partial per (tile, wave row): 64 pixels of the sample; o2m_instnorm_finalize / o2m_conv2d_dots_finalize
+    // add a sample's H W / 64 partials whatever pixels each covers
+    if (d.stats) stats_block_reduce<NT, VPR>(st, csm, d.stats, ((long)b * tps + tis) * 4 + pass, n0, Co, tid);
+    lds_barrier();
+  }
+}
+
 template <int CO>
 int launch_halo(const o2m_conv_desc& d, hipStream_t s) {
   constexpr int lds_main = 43 * 1024 + 2 * CO * 128, lds_epi = 64 * (CO + 4) * 4, lds_red = 16 * 512 * 4;
@@ -1351,6 +1547,36 @@ int launch_halo(const o2m_conv_desc& d, hipStream_t s) {
   }
   O2M_LAUNCH_CHECK();
   return 0;
+}
+
+template <int KS>
+int launch_halo_any(const o2m_conv_desc& d, hipStream_t s) {
+  constexpr int npix = (8 + KS - 1) * (32 + KS - 1);
+  constexpr int lds_main = ((npix + 7) / 8) * 1024 + 2 * 64 * 128, lds_red = 16 * 512 * 4;
+  constexpr int lds = lds_main > lds_red ? lds_main : lds_red;
+  const int Ho = d.H + 2 * d.pad - KS + 1, Wo = d.W + 2 * d.pad - KS + 1;
+  const long tiles = (long)d.B * ((Ho + 7) / 8) * ((Wo + 31) / 32);
+  if (tiles <= 0 || tiles > 0x7fffffffL || d.Co / 64 > 65535) return O2M_ERR_BAD_ARG;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_any_kernel<KS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  {
+    LaunchScope timed(s, 2.0 * d.B * Ho * Wo * d.Co * (double)(KS * KS) * d.Ci, "conv_halo<bf16,%dx%d,8x32x64>", KS, KS);
+    hipLaunchKernelGGL(conv_halo_any_kernel<KS>, dim3((unsigned)tiles, (unsigned)(d.Co / 64)), dim3(512), lds, s, d);
+  }
+  O2M_LAUNCH_CHECK();
+  return 0;
+}
+
+// the layers the clipped halo-tile kernel takes: the 4 x 4 trunk convolutions and their data gradients (64-channel
+// multiples on both sides, zero padding, plain epilogue incl. InstanceNorm partials)
+inline bool halo_any_ok(const o2m_conv_desc& d) {
+  static const int on = [] { const char* e = getenv("O2M_CONV_HALO4"); return e ? atoi(e) : 1; }();
+  if (!on || d.fold_pad || d.dtype != O2M_BF16 || d.KH != 4 || d.KW != 4 || d.pad < 1 || d.pad > 3 || d.pad_mode != O2M_PAD_ZERO ||
+      d.stride > 1 || d.in_scale || d.aux || d.aux_scaled || d.Ci % 64 || d.Co % 64 || d.w_batch_stride)
+    return false;
+  if (d.stats && d.stats_mode != O2M_STATS_MOMENTS) return false;
+  const int Ho = d.H + 2 * d.pad - 4 + 1, Wo = d.W + 2 * d.pad - 4 + 1;
+  // at least one block per CU (two are resident): the 30 x 30 maps at B = 16 give 64 tiles x 8 channel blocks
+  return Ho > 0 && Wo > 0 && (long)d.B * ((Ho + 7) / 8) * ((Wo + 31) / 32) * (d.Co / 64) >= kFillBlocks;
 }
 
 // the layers the halo-tile kernel takes (host side of its preconditions)
@@ -1406,6 +1632,7 @@ int launch_dtype(const o2m_conv_desc& d, hipStream_t s) {
     if (o2m_direct::stem8_ok(d)) return o2m_direct::launch_stem8(d, s);
     if (o2m_direct::fewout_ok(d)) return o2m_direct::launch_fewout(d, s);
     if (halo_ok(d)) return d.Co == 64 ? launch_halo<64>(d, s) : launch_halo<128>(d, s);
+    if (halo_any_ok(d)) return launch_halo_any<4>(d, s);
   }
   // big 8-wave tiles when they still give every CU a block; otherwise the 4-wave 128-wide
   // tiles (small-M layers of the discriminator) so the chip stays filled
@@ -1505,6 +1732,20 @@ extern "C" int o2m_conv2d_dots_finalize(const float* partial, float* dots, int32
                      partial, dots, B * C, C, nchunks);
   O2M_LAUNCH_CHECK();
   return 0;
+}
+
+// partial rows PER SAMPLE the epilogue of the selected kernel writes (0: it cannot emit them)
+extern "C" int32_t o2m_conv2d_stats_chunks(const o2m_conv_desc* d) {
+  if (!d || d->B <= 0 || d->H <= 0 || d->W <= 0 || d->KH <= 0 || d->KW <= 0 || d->pad < 0) return 0;
+  if (d->dtype == O2M_BF16 && !o2m_direct::stem8_ok(*d) && !halo_ok(*d) && halo_any_ok(*d)) {
+    const int Ho = d->H + 2 * d->pad - d->KH + 1, Wo = d->W + 2 * d->pad - d->KW + 1;
+    return 4 * ((Ho + 7) / 8) * ((Wo + 31) / 32);  // one per (clipped 8 x 32 tile, wave row)
+  }
+  const int r = o2m_conv2d_stats_rows(d);
+  if (r <= 0) return 0;
+  const int S = d->stride > 1 ? d->stride : 1;
+  const long howo = (long)((d->H + 2 * d->pad - d->KH) / S + 1) * ((d->W + 2 * d->pad - d->KW) / S + 1);
+  return (int32_t)(howo / r);
 }
 
 extern "C" int32_t o2m_debug_fill_blocks(int32_t n) {
@@ -1611,7 +1852,7 @@ extern "C" int o2m_conv2d_fwd(const o2m_conv_desc* d, void* stream) {
   }
   if (d->stats_mode != O2M_STATS_MOMENTS && d->stats_mode != O2M_STATS_DOT) return O2M_ERR_BAD_ARG;
   if (d->stats && d->stats_mode == O2M_STATS_MOMENTS &&
-      (d->act != O2M_ACT_NONE || d->residual || d->out_scale || o2m_conv2d_stats_rows(d) == 0))
+      (d->act != O2M_ACT_NONE || d->residual || d->out_scale || o2m_conv2d_stats_chunks(d) == 0))
     return O2M_ERR_BAD_ARG;
   if (d->stats && d->stats_mode == O2M_STATS_DOT &&
       (!d->aux || d->act != O2M_ACT_NONE || d->residual || d->bias || o2m_conv2d_stats_rows(d) == 0))

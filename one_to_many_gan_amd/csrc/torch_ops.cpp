@@ -135,9 +135,9 @@ void conv2d_fwd(const Tensor& x, const Tensor& w, Tensor& y, const OptT& in_scal
   d.stride = i32(stride, op);
   d.fold_pad = i32(fold_pad, op);
   if (stats.has_value()) {
-    const int rows = o2m_conv2d_stats_rows(&d);
-    TORCH_CHECK(rows > 0, op, ": this conv cannot emit InstanceNorm partials (Ho*Wo is not a multiple of its row block)");
-    TORCH_CHECK(stats->numel() >= (x.size(0) * Ho * Wo / rows) * Co * 2, op, ": stats workspace too small");
+    const int chunks = o2m_conv2d_stats_chunks(&d);
+    TORCH_CHECK(chunks > 0, op, ": this conv cannot emit InstanceNorm partials (Ho*Wo is not a multiple of its row block)");
+    TORCH_CHECK(stats->numel() >= x.size(0) * chunks * Co * 2, op, ": stats workspace too small");
     d.stats = ptr<float>(stats);
   }
   if (aux.has_value()) {  // style-dot partials instead of InstanceNorm moments (O2M_STATS_DOT)
@@ -208,6 +208,16 @@ int64_t conv2d_stats_rows(const Tensor& x, const Tensor& w, const Tensor& y, int
   d.Co = i32(w.size(0), op); d.KH = i32(w.size(1), op); d.KW = i32(w.size(2), op); d.pad = i32(pad, op);
   d.dtype = is_fp8(x) ? O2M_FP8_E4M3 : dtype_code(x, op); d.stride = i32(stride, op);
   return o2m_conv2d_stats_rows(&d);
+}
+
+int64_t conv2d_stats_chunks(const Tensor& x, const Tensor& w, const Tensor& y, int64_t pad, int64_t stride) {
+  const char* op = "o2m::conv2d_stats_chunks";
+  TORCH_CHECK(x.dim() == 4 && w.dim() == 4 && y.dim() == 4, op, ": x, y are NHWC; w is [Co][KH][KW][Ci]");
+  o2m_conv_desc d{};
+  d.B = i32(x.size(0), op); d.H = i32(x.size(1), op); d.W = i32(x.size(2), op); d.Ci = i32(x.size(3), op);
+  d.Co = i32(w.size(0), op); d.KH = i32(w.size(1), op); d.KW = i32(w.size(2), op); d.pad = i32(pad, op);
+  d.dtype = is_fp8(x) ? O2M_FP8_E4M3 : dtype_code(x, op); d.stride = i32(stride, op);
+  return o2m_conv2d_stats_chunks(&d);
 }
 
 static void fill_wgrad_dims(o2m_wgrad_desc& d, const Tensor& x, const Tensor& dw, int64_t pad, int64_t pad_mode, int64_t splits,
@@ -651,6 +661,7 @@ TORCH_LIBRARY(o2m, m) {
   m.def("amax(Tensor x, Tensor(a!) amax) -> ()");
   m.def("quantize_fp8(Tensor x, Tensor amax, Tensor(a!) y, Tensor(b!) deq) -> ()");
   m.def("conv2d_stats_rows(Tensor x, Tensor w, Tensor y, int pad, int stride) -> int");
+  m.def("conv2d_stats_chunks(Tensor x, Tensor w, Tensor y, int pad, int stride) -> int");
   m.def("instnorm_finalize(Tensor partial, Tensor(a!) mean_rstd, int P, int nchunks, float eps) -> ()");
   m.def("conv2d_wgrad(Tensor x, Tensor gy, Tensor(a!) dw, Tensor? in_scale, Tensor? gy_scale, int pad, int pad_mode, int splits, "
         "int stride, Tensor(b!)? slabs=None, int kernel_hint=0) -> ()");
@@ -708,6 +719,7 @@ TORCH_LIBRARY(o2m, m) {
   m.impl("instnorm_stats", &instnorm_stats);      \
   m.impl("instnorm_finalize", &instnorm_finalize); \
   m.impl("conv2d_stats_rows", &conv2d_stats_rows); \
+  m.impl("conv2d_stats_chunks", &conv2d_stats_chunks); \
   m.impl("conv2d_dots_finalize", &conv2d_dots_finalize); \
   m.impl("lsgan_fwd", &lsgan_fwd);                \
   m.impl("lsgan_bwd", &lsgan_bwd);                \

@@ -702,13 +702,13 @@ class _ConvFn(torch.autograd.Function):
             if prep.fp8_ok(False, B * ho * wo):
                 win, deq = prep.get_fp8(False)
                 xin = _quantize(x, torch.float8_e4m3fn, deq[0:2])
-            rows = H.conv2d_stats_rows(xin, win, y, pad=pad) if _FUSED_IN_STATS else 0
+            # partial rows per sample the selected kernel's epilogue writes (0: none -- separate statistics pass)
+            nchunks = H.conv2d_stats_chunks(xin, win, y, pad=pad) if _FUSED_IN_STATS else 0
             part = None
-            if rows:
-                nchunks = ho * wo // rows
+            if nchunks:
                 part = torch.empty(B * nchunks * prep.cop * 2, dtype=torch.float32, device=x.device)
             H.conv2d_fwd(xin, win, y, bias=bias_p, pad=pad, pad_mode=pad_mode, act=act, stats=part, deq=deq)
-            if rows:
+            if nchunks:
                 H.instnorm_finalize(part, mr, ho * wo, nchunks, stats_eps)
             else:
                 ws = torch.empty(H.instnorm_ws_floats(B, ho * wo, prep.cop), dtype=torch.float32, device=x.device)

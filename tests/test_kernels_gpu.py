@@ -290,6 +290,68 @@ def test_direct_conv_kernels_match_torch_fp32(case):
     assert worst < 2e-2, worst
 
 
+TRUNK_CONVS = [
+    # B, H, W, Ci, Co, pad, extras            (conv_halo_any_kernel<4>: 4 x 4 taps, clipped 8 x 32 tiles, 64 channels per block)
+    (4, 127, 127, 64, 128, 1, "bias+stats"),   # D / S trunk (builder.py:272): 126 x 126 out, statistics from clipped tiles
+    (4, 63, 63, 128, 256, 1, "bias+stats"),    # 62 x 62
+    (8, 31, 31, 256, 512, 1, "bias+stats"),    # 30 x 30: one tile column, eight channel blocks
+    (16, 30, 30, 512, 256, 2, "plain"),        # data gradient of the last trunk conv: pad 2, 31 x 31 out
+    (4, 126, 126, 128, 64, 2, "plain"),        # data gradient of the first: 127 x 127 out
+    (2, 20, 45, 64, 64, 1, "bias+lrelu"),      # ragged both ways (routed there by the test hook)
+]
+
+
+@pytest.mark.parametrize("case", TRUNK_CONVS, ids=lambda c: "x".join(map(str, c[:6])) + "-" + c[6])
+def test_clipped_halo_kernel_matches_torch_fp32(case):
+    """The 4 x 4 trunk convolutions on odd-sized maps and their data gradients on the clipped halo-tile kernel against
+    torch's fp32 convolution of the same bf16-valued operands; the InstanceNorm partials of the clipped tiles (4 per
+    tile, o2m_conv2d_stats_chunks of them per sample) through o2m_instnorm_finalize against the reference's moments."""
+    import torch.nn.functional as F
+
+    from one_to_many_gan_amd import _hip as H
+
+    B, Hh, Ww, Ci, Co, pad, extras = case
+    torch.manual_seed(29)
+    dev, dt = "cuda", torch.bfloat16
+    x = torch.randn(B, Hh, Ww, Ci, device=dev).to(dt)
+    w = (torch.randn(Co, 4, 4, Ci, device=dev) / (Ci * 16) ** 0.5).to(dt)
+    ho, wo = Hh + 2 * pad - 3, Ww + 2 * pad - 3
+    y = torch.full((B, ho, wo, Co), float("nan"), device=dev, dtype=dt)
+    bias = torch.randn(Co, device=dev) if "bias" in extras else None
+    act = H.ACT_LRELU if "lrelu" in extras else H.ACT_NONE
+    prev = H.debug_fill_blocks(1) if B == 2 else None
+    try:
+        part = chunks = None
+        if "stats" in extras:
+            chunks = H.conv2d_stats_chunks(x, w, y, pad=pad)
+            assert chunks == 4 * ((ho + 7) // 8) * ((wo + 31) // 32), chunks
+            part = torch.full((B * chunks * Co * 2,), float("nan"), device=dev)
+        H.launch_timing(True)
+        try:
+            H.conv2d_fwd(x, w, y, bias=bias, pad=pad, pad_mode=H.PAD_ZERO, act=act, stats=part)
+            names = set(H.launch_timing_read())
+        finally:
+            H.launch_timing(False)
+    finally:
+        if prev is not None:
+            H.debug_fill_blocks(prev)
+    assert names == {"conv_halo<bf16,4x4,8x32x64>"}, names
+    ref = F.conv2d(F.pad(x.float().permute(0, 3, 1, 2), (pad,) * 4), w.float().permute(0, 3, 1, 2), bias)
+    if part is not None:
+        mr = torch.empty(B, Co, 2, device=dev)
+        H.instnorm_finalize(part, mr, ho * wo, chunks, 1e-5)
+        assert float((mr[..., 0] - ref.mean((2, 3))).abs().max()) < 1e-4
+        rstd = (ref.var((2, 3), unbiased=False) + 1e-5).rsqrt()
+        assert float(((mr[..., 1] - rstd) / rstd).abs().max()) < 1e-4
+    if act == H.ACT_LRELU:
+        ref = F.leaky_relu(ref, 0.2)
+    ref = ref.permute(0, 2, 3, 1)
+    assert torch.isfinite(y.float()).all()  # every output element written
+    err = float((y.float() - ref).norm() / ref.norm())
+    assert err < 3e-3, err
+    assert float((y.float() - ref).abs().max() / ref.abs().max()) < 2e-2
+
+
 @pytest.mark.parametrize("fmt", [torch.float8_e4m3fn, torch.float8_e5m2], ids=["e4m3", "e5m2"])
 def test_fp8_quantisation_matches_torch(fmt):
     """o2m_amax + o2m_quantize_fp8 (per-tensor scale FMT_MAX / amax, round to nearest even, OCP formats)
