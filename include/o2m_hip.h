@@ -290,6 +290,21 @@ size_t o2m_conv2d_wgrad_slab_floats(const o2m_wgrad_desc* d);
  */
 int o2m_wgrad_finalize(float* acc, float* gq, const float* w32, float* grad, int32_t Co, int32_t Ci,
                        int32_t KK, int32_t Cop, int32_t Cip, float c, void* stream);
+/* The same for EVERY layer a backward pass left pending, in one launch (+ one that clears the dL/dQ tables when
+ * any_gq != 0): `jobs` is a DEVICE array; job j owns blocks [first_block_j, first_block_j + o2m_wgrad_finalize_blocks(Cop,
+ * KK, Cip)), first_block ascending from 0, total_blocks = their sum.  29 launches per D+G step become 2 + 2. */
+typedef struct o2m_wfin_job {
+  float* acc;        /* [Cop][KK][Cip] accumulator (cleared)        */
+  float* gq;         /* [Cop][Cip] dL/dQ or NULL (cleared)          */
+  const float* w32;  /* [Cop][KK][Cip] W*c (read when gq != NULL)   */
+  float* grad;       /* [Co][Ci][KK] the parameter's .grad (+=)     */
+  int32_t Co, Ci, KK, Cop, Cip;
+  float c;
+  int32_t first_block;
+  int32_t reserved;
+} o2m_wfin_job;
+int32_t o2m_wgrad_finalize_blocks(int32_t Cop, int32_t KK, int32_t Cip);
+int o2m_wgrad_finalize_batched(const o2m_wfin_job* jobs, int32_t n_jobs, int32_t total_blocks, int32_t any_gq, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Backward of the fused epilogue: gu = g * act'(y), plus the per-(b,c) sums the

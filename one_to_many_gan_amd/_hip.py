@@ -33,7 +33,7 @@ ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 PAD_ZERO, PAD_REFLECT = 0, 1
 RED_L1, RED_SQ, RED_MOM = 0, 1, 2
 STATS_MOMENTS, STATS_DOT = 0, 1
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -52,6 +52,14 @@ class PrepJob(C.Structure):
     """o2m_prep_job (include/o2m_hip.h)."""
 
     _fields_ = [("w", _vp), ("full", _vp), ("w_f", _vp), ("w_d", _vp), ("q", _vp), ("qt", _vp),
+                ("Co", _i32), ("Ci", _i32), ("KK", _i32), ("Cop", _i32), ("Cip", _i32), ("c", _f32),
+                ("first_block", _i32), ("reserved", _i32)]
+
+
+class WfinJob(C.Structure):
+    """o2m_wfin_job (include/o2m_hip.h)."""
+
+    _fields_ = [("acc", _vp), ("gq", _vp), ("w32", _vp), ("grad", _vp),
                 ("Co", _i32), ("Ci", _i32), ("KK", _i32), ("Cop", _i32), ("Cip", _i32), ("c", _f32),
                 ("first_block", _i32), ("reserved", _i32)]
 
@@ -107,6 +115,8 @@ SIGNATURES = {
     "o2m_unpack_nhwc": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "o2m_lsgan_fwd": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _vp]),
     "o2m_lsgan_bwd": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _vp]),
+    "o2m_wgrad_finalize_blocks": (_i32, [_i32, _i32, _i32]),
+    "o2m_wgrad_finalize_batched": (_i32, [_vp, _i32, _i32, _i32, _vp]),
     "o2m_reduce_blocks": (_i32, [_i64]),
     "o2m_reduce_fwd": (_i32, [_vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp]),
     "o2m_reduce_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp]),
@@ -341,6 +351,16 @@ def wgrad_finalize(acc, gq, w32, grad, co, ci, c):
 def prepare_weights(w, full, w_f, w_d, q, qt, c):
     """W*c in the kernel layouts (see o2m_prepare_weights); ``w`` is the raw (Co,Ci,KH,KW) parameter."""
     ops().prepare_weights(w, full, w_f, w_d, q, qt, c)
+
+
+def wgrad_finalize_blocks(cop, kk, cip):
+    return int(ops().wgrad_finalize_blocks(cop, kk, cip))
+
+
+def wgrad_finalize_batched(jobs, n_jobs, total_blocks, any_gq, touched):
+    """Every pending layer's accumulators -> .grad in one launch; ``jobs``: uint8 device tensor of WfinJob records,
+    ``touched``: the tensors the jobs name (accumulators, dL/dQ tables, gradients) for the schema's mutation list."""
+    ops().wgrad_finalize_batched(jobs, n_jobs, total_blocks, bool(any_gq), touched)
 
 
 def prepare_weights_batched(jobs, n_jobs, total_blocks, dtype, outs):

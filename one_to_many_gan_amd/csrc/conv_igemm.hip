@@ -1471,6 +1471,9 @@ __global__ __launch_bounds__(512, 4) void conv_halo_any_kernel(const o2m_conv_de
   float* csm = reinterpret_cast<float*>(smem);
   T* __restrict__ Y = static_cast<T*>(d.y);
   const T* __restrict__ R = static_cast<const T*>(d.residual);
+  const T* __restrict__ AUX = static_cast<const T*>(d.aux);
+  T* __restrict__ AUXS = static_cast<T*>(d.aux_scaled);
+  const bool dot_mode = d.stats && d.stats_mode == O2M_STATS_DOT;
   const int act = d.act;
   const bool stream_out = (size_t)d.B * Ho * Wo * Co * 2 >= ((size_t)64 << 20);
   const int ec8 = tid % VPR, erow = tid / VPR, en = n0 + ec8 * 8;
@@ -1512,9 +1515,20 @@ __global__ __launch_bounds__(512, 4) void conv_halo_any_kernel(const o2m_conv_de
       const f32x4 va = *reinterpret_cast<const f32x4*>(csm + row * CSTR + ec8 * 8);
       const f32x4 vb = *reinterpret_cast<const f32x4*>(csm + row * CSTR + ec8 * 8 + 4);
       float o[8] = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
+      if (dot_mode) {  // style-dot partials sum acc * aux (and aux * out_scale on its way past): see conv3x3_halo_kernel
+        float xv[8];
+        load8x(AUX + off, xv, stream_out);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) st[q] += o[q] * xv[q];
+        if (AUXS) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) xv[q] *= esc[q];
+          store8x(AUXS + off, xv, stream_out);
+        }
+      }
 #pragma unroll
       for (int q = 0; q < 8; ++q) o[q] = o[q] * esc[q] + ebias[q];
-      if (d.stats) {
+      if (d.stats && !dot_mode) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) { st[q] += o[q]; st[8 + q] += o[q] * o[q]; }
       }
@@ -1631,7 +1645,13 @@ int launch_dtype(const o2m_conv_desc& d, hipStream_t s) {
   if constexpr (sizeof(T) == 2) {
     if (o2m_direct::stem8_ok(d)) return o2m_direct::launch_stem8(d, s);
     if (o2m_direct::fewout_ok(d)) return o2m_direct::launch_fewout(d, s);
-    if (halo_ok(d)) return d.Co == 64 ? launch_halo<64>(d, s) : launch_halo<128>(d, s);
+    if (halo_ok(d)) {
+      // O2M_HALO128_SPLIT=1 (A/B): the Co = 128 layers as two 64-channel blocks of the clipped kernel (no spills, the
+      // patch ingested twice) instead of conv3x3_halo_kernel<128> (25 VGPRs spilled)
+      static const int split128 = [] { const char* e = getenv("O2M_HALO128_SPLIT"); return e ? atoi(e) : 0; }();
+      if (d.Co == 128 && split128) return launch_halo_any<3>(d, s);
+      return d.Co == 64 ? launch_halo<64>(d, s) : launch_halo<128>(d, s);
+    }
     if (halo_any_ok(d)) return launch_halo_any<4>(d, s);
   }
   // big 8-wave tiles when they still give every CU a block; otherwise the 4-wave 128-wide

@@ -1038,6 +1038,44 @@ __global__ __launch_bounds__(NT) void wgrad_finalize_kernel(float* acc, float* g
     }
   }
 }
+// every pending layer of a backward pass in one launch (+ one for the dL/dQ tables): blockIdx -> job through the
+// first_block table, FIN_PER_BLOCK consecutive kernel-layout elements per block
+constexpr int FIN_PER_BLOCK = NT * 8;
+__global__ __launch_bounds__(NT) void wgrad_finalize_batched_kernel(const o2m_wfin_job* __restrict__ jobs, int n_jobs) {
+  int j = 0;
+  while (j + 1 < n_jobs && (int)blockIdx.x >= jobs[j + 1].first_block) ++j;  // uniform
+  const o2m_wfin_job jb = jobs[j];
+  const long n = (long)jb.Cop * jb.KK * jb.Cip;
+  const long t0 = (long)((int)blockIdx.x - jb.first_block) * FIN_PER_BLOCK + threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const long t = t0 + (long)k * NT;
+    if (t >= n) break;
+    const int i = (int)(t % jb.Cip);
+    const long r = t / jb.Cip;
+    const int kk = (int)(r % jb.KK);
+    const int o = (int)(r / jb.KK);
+    float v = jb.acc[t];
+    jb.acc[t] = 0.f;
+    if (o < jb.Co && i < jb.Ci) {
+      if (jb.gq) v += 2.f * jb.gq[(size_t)o * jb.Cip + i] * jb.w32[t];
+      jb.grad[((size_t)o * jb.Ci + i) * jb.KK + kk] += jb.c * v;
+    }
+  }
+}
+__global__ __launch_bounds__(NT) void wgrad_clear_gq_batched_kernel(const o2m_wfin_job* __restrict__ jobs, int n_jobs) {
+  int j = 0;
+  while (j + 1 < n_jobs && (int)blockIdx.x >= jobs[j + 1].first_block) ++j;
+  const o2m_wfin_job jb = jobs[j];
+  if (!jb.gq) return;
+  const long n = (long)jb.Cop * jb.Cip;  // (<= the job's element count: its blocks cover it)
+  const long t0 = (long)((int)blockIdx.x - jb.first_block) * FIN_PER_BLOCK + threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const long t = t0 + (long)k * NT;
+    if (t < n) jb.gq[t] = 0.f;
+  }
+}
 __global__ void clear_kernel(float* p, long n) {
   for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) p[t] = 0.f;
 }
@@ -1177,7 +1215,7 @@ void close(int slot, hipStream_t s) {
 
 extern "C" {
 
-int o2m_abi_version(void) { return 20; }
+int o2m_abi_version(void) { return 21; }
 
 int32_t o2m_launch_timing(int32_t enable) {
   std::lock_guard<std::mutex> lock(o2m_timing::g_mu);
@@ -1574,6 +1612,23 @@ int o2m_wgrad_finalize(float* acc, float* gq, const float* w32, float* grad, int
   O2M_LAUNCH_CHECK();
   if (gq) {
     hipLaunchKernelGGL(clear_kernel, dim3(grid_for((long)Cop * Cip)), dim3(NT), 0, s, gq, (long)Cop * Cip);
+    O2M_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+int32_t o2m_wgrad_finalize_blocks(int32_t Cop, int32_t KK, int32_t Cip) {
+  if (Cop <= 0 || KK <= 0 || Cip <= 0) return 0;
+  return (int32_t)(((long)Cop * KK * Cip + FIN_PER_BLOCK - 1) / FIN_PER_BLOCK);
+}
+
+int o2m_wgrad_finalize_batched(const o2m_wfin_job* jobs, int32_t n_jobs, int32_t total_blocks, int32_t any_gq, void* stream) {
+  if (!jobs || n_jobs <= 0 || total_blocks <= 0) return O2M_ERR_BAD_ARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(wgrad_finalize_batched_kernel, dim3((unsigned)total_blocks), dim3(NT), 0, s, jobs, n_jobs);
+  O2M_LAUNCH_CHECK();
+  if (any_gq) {
+    hipLaunchKernelGGL(wgrad_clear_gq_batched_kernel, dim3((unsigned)total_blocks), dim3(NT), 0, s, jobs, n_jobs);
     O2M_LAUNCH_CHECK();
   }
   return 0;

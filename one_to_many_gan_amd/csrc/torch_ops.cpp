@@ -285,6 +285,20 @@ void prepare_weights(const Tensor& w, Tensor& full, Tensor& w_f, Tensor& w_d, co
                                      static_cast<float>(c), dt_w_f, stream));
 }
 
+int64_t wgrad_finalize_blocks(int64_t cop, int64_t kk, int64_t cip) {
+  return o2m_wgrad_finalize_blocks(static_cast<int32_t>(cop), static_cast<int32_t>(kk), static_cast<int32_t>(cip));
+}
+
+void wgrad_finalize_batched(const Tensor& jobs, int64_t n_jobs, int64_t total_blocks, bool any_gq, at::TensorList touched) {
+  const char* op = "o2m::wgrad_finalize_batched";
+  chk(jobs, op, "jobs");
+  TORCH_CHECK(jobs.scalar_type() == at::kByte && jobs.numel() >= n_jobs * static_cast<int64_t>(sizeof(o2m_wfin_job)), op,
+              ": jobs is a uint8 device tensor of n_jobs o2m_wfin_job records");
+  for (const Tensor& t : touched) chk_f32(t, op, "touched[]");  // accumulators, dL/dQ tables, gradients the records point at
+  O2M_CALL(op, jobs, o2m_wgrad_finalize_batched(static_cast<const o2m_wfin_job*>(ptr(jobs)), i32(n_jobs, op), i32(total_blocks, op),
+                                               any_gq ? 1 : 0, stream));
+}
+
 void prepare_weights_batched(const Tensor& jobs, int64_t n_jobs, int64_t total_blocks, int64_t dtype, at::TensorList outs) {
   const char* op = "o2m::prepare_weights_batched";
   chk(jobs, op, "jobs");
@@ -670,6 +684,8 @@ TORCH_LIBRARY(o2m, m) {
   m.def("wgrad_finalize(Tensor(a!) acc, Tensor(b!)? gq, Tensor w32, Tensor(c!) grad, int co, int ci, float c) -> ()");
   m.def("prepare_weights(Tensor w, Tensor(a!) full, Tensor(b!) w_f, Tensor(c!) w_d, Tensor(d!)? q, Tensor(e!)? qt, float c) -> ()");
   m.def("prepare_weights_batched(Tensor jobs, int n_jobs, int total_blocks, int dtype, Tensor(a!)[] outs) -> ()");
+  m.def("wgrad_finalize_blocks(int cop, int kk, int cip) -> int", &wgrad_finalize_blocks);
+  m.def("wgrad_finalize_batched(Tensor jobs, int n_jobs, int total_blocks, bool any_gq, Tensor(a!)[] touched) -> ()");
   m.def("modulate_weights(Tensor w32, Tensor s, Tensor(a!) out) -> ()");
   m.def("style_fwd(Tensor w, Tensor ws, Tensor bs, Tensor? qt, Tensor(a!) s, Tensor(b!)? d, int ci, float cs, float eps) -> ()");
   m.def("style_bwd(Tensor? sums, Tensor? bias, Tensor? dots, Tensor s, Tensor? d, Tensor? q, Tensor w, Tensor ws, Tensor(a!)? e, "
@@ -709,6 +725,7 @@ TORCH_LIBRARY(o2m, m) {
   m.impl("wgrad_finalize", &wgrad_finalize);      \
   m.impl("prepare_weights", &prepare_weights);    \
   m.impl("prepare_weights_batched", &prepare_weights_batched); \
+  m.impl("wgrad_finalize_batched", &wgrad_finalize_batched); \
   m.impl("modulate_weights", &modulate_weights);  \
   m.impl("amax", &amax);                          \
   m.impl("quantize_fp8", &quantize_fp8);          \

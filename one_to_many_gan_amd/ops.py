@@ -514,6 +514,56 @@ def _finalize_layer(prep):
             hook(p)
 
 
+# O2M_BATCHED_FINALIZE=0: one o2m_wgrad_finalize launch (+ a clear launch for modulated layers) per pending layer at the
+# end of backward (29 + 16 launches per D+G step) instead of one batched launch (+ one) per backward pass
+_BATCHED_FINALIZE = _os.environ.get("O2M_BATCHED_FINALIZE", "1") == "1"
+_FIN_JOBS: dict = {}
+
+
+def _finalize_batched(live) -> bool:
+    """Every pending layer's kernel-layout accumulators -> ``weight.grad`` in ONE launch (o2m_wgrad_finalize_batched).
+    Falls back (False) when a layer is unusual: no fp32 contiguous .grad, CPU tensors."""
+    import ctypes
+
+    for prep in live:
+        w = prep.weight
+        if not w.is_cuda:
+            return False
+        if w.grad is None:
+            w.grad = torch.zeros_like(w)
+        if w.grad.dtype != torch.float32 or not w.grad.is_contiguous():
+            return False
+    for prep in live:
+        if prep.dw2_used:
+            prep.fold_s2d()
+    w32s = [prep.get()[3] for prep in live]
+    ident = tuple((prep.dw_acc.data_ptr(), prep.gq_acc.data_ptr() if prep.gq_acc is not None else 0, w.data_ptr(),
+                   prep.weight.grad.data_ptr()) for prep, w in zip(live, w32s))
+    hit = _FIN_JOBS.get(ident)
+    if hit is None:
+        if len(_FIN_JOBS) > 16:
+            _FIN_JOBS.clear()
+        jobs, first = (H.WfinJob * len(live))(), 0
+        for j, (prep, w32) in enumerate(zip(live, w32s)):
+            jobs[j] = H.WfinJob(prep.dw_acc.data_ptr(), prep.gq_acc.data_ptr() if prep.gq_acc is not None else None,
+                                w32.data_ptr(), prep.weight.grad.data_ptr(), prep.co, prep.ci, prep.kh * prep.kw, prep.cop,
+                                prep.cip, prep.c, first, 0)
+            first += H.wgrad_finalize_blocks(prep.cop, prep.kh * prep.kw, prep.cip)
+        raw = torch.frombuffer(bytearray(ctypes.string_at(ctypes.addressof(jobs), ctypes.sizeof(jobs))), dtype=torch.uint8)
+        hit = _FIN_JOBS[ident] = (raw.to(live[0].weight.device), len(live), first,
+                                  any(prep.gq_acc is not None for prep in live))
+    touched = [t for prep in live for t in (prep.dw_acc, prep.gq_acc, prep.weight.grad) if t is not None]
+    H.wgrad_finalize_batched(hit[0], hit[1], hit[2], hit[3], touched)
+    for prep in live:
+        prep.pending = False
+        prep.fwd_uses = prep.bwd_uses = 0
+        for p in (prep.weight, *getattr(prep, "direct_style", ())):
+            hook = GRAD_READY_HOOKS.get(p)
+            if hook is not None:
+                hook(p)
+    return True
+
+
 def _finalize_weight_grads():
     """End of a backward pass (autograd engine callback): finalises every layer that was not
     already finalised when its last recorded use was reduced (``_ConvFn.backward``) -- e.g. a
@@ -525,9 +575,11 @@ def _finalize_weight_grads():
         torch.cuda.current_stream(dev).wait_stream(wst)
     for dev, gst in _GSTREAM.items():  # style gradients accumulated by a group that ran on its own stream
         torch.cuda.current_stream(dev).wait_stream(gst)
-    for prep in pend:
-        if prep.pending:
-            _finalize_layer(prep)
+    live = [prep for prep in pend if prep.pending]
+    if len(live) > 1 and _BATCHED_FINALIZE and _finalize_batched(live):
+        return
+    for prep in live:
+        _finalize_layer(prep)
 
 
 class _ZeroPool:
@@ -589,11 +641,11 @@ _WGRAD_HALO = _os.environ.get("O2M_WGRAD_HALO", "1") != "0" and _os.environ.get(
 # + o2m_conv2d_reflect_border for the ring the crop leaves out.  Same-box A/B (gpurun_out/r04f, r04g, r04h): the tail
 # launches shrink by 0.86 ms per step, the border launches cost 1.43 -> 1.18 -> 0.78 ms over three versions of the
 # kernel (L2-traffic-bound: conv_direct.hip) and the step stays 0.5 ms SLOWER.  Default: the padded 66 x 66 domain + fold.
-_BORDER_DGRAD = _os.environ.get("O2M_BORDER_DGRAD", "0") == "1"
+_BORDER_DGRAD = int(_os.environ.get("O2M_BORDER_DGRAD", "0"))  # 1: the plain (encoder) convs only; 2: the modulated ones too
 
 
-def _border_dgrad_ok(prep, g, Hh, Ww, pad, pad_mode) -> bool:
-    return (_BORDER_DGRAD and pad_mode == H.PAD_REFLECT and pad == 1 and prep.kh == 3 and prep.kw == 3
+def _border_dgrad_ok(prep, g, Hh, Ww, pad, pad_mode, modulated=False) -> bool:
+    return (_BORDER_DGRAD >= (2 if modulated else 1) and pad_mode == H.PAD_REFLECT and pad == 1 and prep.kh == 3 and prep.kw == 3
             and g.dtype == torch.bfloat16 and not deterministic() and prep.cop % 64 == 0 and prep.cip % 64 == 0
             and min(Hh, Ww) >= 4)
 
@@ -866,7 +918,8 @@ class _ConvFn(torch.autograd.Function):
                 res_in = None
             else:
                 fold = pad if pad_mode == H.PAD_REFLECT else 0  # what the pass behind the GEMM still has to fold
-                border = s is not None and _border_dgrad_ok(prep, g, Hh, Ww, pad, pad_mode) and not prep.fp8_ok(True, B * hp * wp)
+                border = (s is not None and _border_dgrad_ok(prep, g, Hh, Ww, pad, pad_mode, modulated=True)
+                          and not prep.fp8_ok(True, B * hp * wp))
                 if border:  # modulated conv behind ReflectionPad2d(1): cropped-domain conv + border ring, nothing left to fold
                     gxp = torch.empty((B, Hh, Ww, cip), dtype=g.dtype, device=dev)
                     H.conv2d_fwd(gu, w_d, gxp, pad=1, pad_mode=H.PAD_ZERO, act=H.ACT_NONE)

@@ -1028,6 +1028,55 @@ def test_batched_weight_preparation_equals_the_per_layer_launches():
     pk.set_precision("bf16")
 
 
+def test_batched_weight_gradient_finalisation_equals_the_per_layer_launches():
+    """ops._finalize_batched: every pending layer's accumulators -> .grad in ONE launch (o2m_wgrad_finalize_batched)
+    against the per-layer o2m_wgrad_finalize launches, bit for bit: plain and modulated layers (dL/dQ term), padded
+    channel counts, += into an existing gradient, accumulators and dL/dQ tables cleared."""
+    import one_to_many_gan_amd as pk
+    from one_to_many_gan_amd import ops
+    from one_to_many_gan_amd.model import builder
+
+    pk.set_precision("bf16")
+    torch.manual_seed(5)
+    net = builder.Generator(3, 6, (32, 32), 8, 3, start_filters=8).cuda()
+    preps = [m._prepared() for m in net.modules() if hasattr(m, "_prepared")]
+    assert any(p.need_q for p in preps) and not all(p.need_q for p in preps)
+    accs, gqs, g0 = [], [], []
+    for p in preps:
+        p.get()
+        p.dw_acc = torch.zeros((p.cop, p.kh, p.kw, p.cip), device="cuda")  # (what PreparedWeights.accumulators allocates)
+        p.gq_acc = torch.zeros((p.cop, p.cip), device="cuda") if p.need_q else None
+        accs.append(torch.randn_like(p.dw_acc))
+        gqs.append(None if p.gq_acc is None else torch.randn_like(p.gq_acc))
+        g0.append(torch.randn_like(p.weight))
+
+    def load():
+        for p, a, q, g in zip(preps, accs, gqs, g0):
+            p.dw_acc.copy_(a)
+            if q is not None:
+                p.gq_acc.copy_(q)
+            p.weight.grad = g.clone()
+            p.pending, p.fwd_uses, p.bwd_uses = True, 1, 1
+
+    load()
+    for p in preps:
+        ops._finalize_layer(p)
+    want = [p.weight.grad.clone() for p in preps]
+    load()
+    assert ops._finalize_batched(preps)
+    torch.cuda.synchronize()
+    for p, w in zip(preps, want):
+        assert torch.equal(p.weight.grad, w)
+        assert not p.pending and p.fwd_uses == 0 and p.bwd_uses == 0
+        assert float(p.dw_acc.abs().max()) == 0.0
+        assert p.gq_acc is None or float(p.gq_acc.abs().max()) == 0.0
+    # a second pass through the cached job table
+    load()
+    assert ops._finalize_batched(preps)
+    for p, w in zip(preps, want):
+        assert torch.equal(p.weight.grad, w)
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
 def test_fused_instance_norm_activation_downsample_matches_the_two_passes(dt):
     """o2m_instnorm_act_resample2d / o2m_instnorm_resample_bwd (InstanceNorm + (Leaky)ReLU + DownSample as one pass,
