@@ -1339,6 +1339,212 @@ __global__ __launch_bounds__(512, 4) void conv3x3_halo_kernel(const o2m_conv_des
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Four-wave form of the halo tile for Co = 128 ("h3w").  conv3x3_halo_kernel<128> needs its 64 accumulators + fragments +
+// epilogue state in 128 VGPRs (two 8-wave blocks per CU): it spills 25 registers and its epilogue takes the 8 x 32 x 128
+// fp32 tile through LDS in four barrier-separated passes -- at Ci = 64 (K = 576: the 64 <-> 128-channel layers at
+// 256 x 256) that epilogue is as long as the nine taps and the kernel ran at 0.26-0.32 of peak (profiles/README.md).
+// Here a block is FOUR waves (one per SIMD, 256 VGPRs each, still two blocks per CU = two independent waves per SIMD):
+//  * wave w owns image rows 2 w, 2 w + 1 of the tile (64 pixels) x all 128 channels: 128 accumulator VGPRs, per tap and
+//    k-step 4 pixel + 8 filter fragment reads for 32 MFMAs (0.375 ds_read_b128 per MFMA, 0.5 before);
+//  * the filter is the A operand and its rows sit permuted in LDS (as in conv_igemm_p8_kernel), so a lane's accumulators
+//    are 8 CONSECUTIVE channels of one pixel: the epilogue goes straight from registers to 16-B global stores -- no LDS
+//    staging, no barrier, a wave leaves when its own stores are out, and the partner block's MFMAs fill the SIMD;
+//  * one barrier per tap (4 waves): { wait for this tap's filter ; barrier ; issue the next tap's fills ; 64 MFMAs }.
+// Same patch / filter images, preconditions and partial-statistics rows (one per (tile, wave) = 64 pixels) as the 8-wave form.
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_w4_kernel(const o2m_conv_desc d) {
+  using T = unsigned short;
+  constexpr int CO = 128, TH = 8, TW = 32, PW = TW + 2, NPIX = (TH + 2) * PW;  // 340 patch pixels
+  constexpr int PFILLS = (NPIX + 7) / 8;                                       // 43 fills of 8 pixels
+  constexpr int PATCH_B = PFILLS * 1024;
+  constexpr int WB = CO * 128;  // one filter tap of one chunk: 128 rows x 64 channels
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* patch = smem;
+  char* wbuf = smem + PATCH_B;
+  typedef __attribute__((address_space(3))) void lds_void;
+
+  const int H = d.H, W = d.W, Ci = d.Ci, Co = d.Co;
+  const int K = 9 * Ci;
+  const int tiles_x = W / TW, tiles_y = H / TH, tps = tiles_x * tiles_y;
+  const int tile = xcd_tile_order(blockIdx.x, gridDim.x);
+  const int b = tile / tps, tis = tile - b * tps;
+  const int ty0 = (tis / tiles_x) * TH, tx0 = (tis % tiles_x) * TW;
+  const rsrc_t xr = make_rsrc(d.x, (unsigned)((size_t)d.B * H * W * Ci * 2));
+  const rsrc_t wr = make_rsrc(static_cast<const char*>(d.w) + (size_t)b * d.w_batch_stride * 2, (unsigned)((size_t)Co * K * 2));
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+
+  // ---- patch fills: fill f = 4 j + wave covers patch pixels 8 f .. 8 f + 7; lane l owns slot (l & 7) of pixel 8 f + (l >> 3)
+  unsigned poff[11];
+#pragma unroll
+  for (int j = 0; j < 11; ++j) {
+    const int f = 4 * j + wave;
+    const int pp = 8 * f + (lane >> 3);
+    const int c = (lane & 7) ^ ((pp >> 1) & 7);
+    const int py = pp / PW, px = pp - py * PW;
+    const int gy = ty0 + py - 1, gx = tx0 + px - 1;
+    const bool ok = f < PFILLS && pp < NPIX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+    poff[j] = ok ? (unsigned)(((b * H + gy) * W + gx) * Ci + c * 8) * 2u : OOB_OFF;
+  }
+  auto issue_patch = [&](int cb) {
+#pragma unroll
+    for (int j = 0; j < 11; ++j) {
+      const int f = 4 * j + wave;
+      if (f >= PFILLS) continue;  // wave-uniform
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void*)(patch + f * 1024), 16, (int)poff[j], cb * 2, 0, 0);
+    }
+  };
+  // ---- filter fills: tile_off's swizzle, lane l of the fill of 8-row group q owns linear slot 64 q + l; LDS row rho holds
+  // output channel 32 (rho >> 5) + 8 ((rho >> 2) & 3) + 4 ((rho >> 4) & 1) + (rho & 3) (see the epilogue)
+  unsigned woff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int q = 4 * wave + j;
+    const int pr = 4 * q + (lane >> 4);
+    const int rho = 2 * pr + (((lane & 15) ^ (pr & 15)) >> 3), chk = ((lane & 15) ^ (pr & 15)) & 7;
+    const int n = 32 * (rho >> 5) + 8 * ((rho >> 2) & 3) + 4 * ((rho >> 4) & 1) + (rho & 3);
+    woff[j] = (unsigned)(n * K + chk * 8) * 2u;
+  }
+  auto issue_w = [&](int tap, int cb, int buf) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void*)(wbuf + buf * WB + (4 * wave + j) * 1024), 16, (int)woff[j],
+                                               (tap * Ci + cb) * 2, 0, 0);
+  };
+
+  // ---- fragments: lane l holds row (l & 15) of a 16-row tile and reduction elements 8 (l >> 4) + 32 ks .. + 7
+  const int c0 = lane >> 4;
+  const int ppb0 = 2 * wave * PW + (lane & 15);  // patch pixel of this lane at tap (0, 0), pixel tile 0
+  const int fb0 = tile_off(lane & 15, c0);
+
+  f32x4_t acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](const int toff, const int buf) {
+    int aoff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {  // pixel tile i: image row (i >> 1) of the wave's two, pixels 16 (i & 1) .. + 15
+      const int pp = ppb0 + (toff + (i >> 1) * PW + (i & 1) * 16);
+      aoff[i] = (pp << 7) | ((c0 ^ ((pp >> 1) & 7)) << 4);
+    }
+    const char* wb = wbuf + buf * WB;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 px[4], wf[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) px[i] = *reinterpret_cast<const bf16x8*>(patch + (aoff[i] ^ (ks << 6)));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(wb + ((fb0 ^ (((j & 1) << 7) | (ks << 6))) + j * 2048));
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], px[i], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  // ---- main loop: per 64-channel chunk, the patch once and the nine taps from it ------------------------
+  for (int cb = 0; cb < Ci; cb += 64) {
+    if (cb) __syncthreads();  // every wave is done with the previous chunk's patch and filter buffers
+    issue_patch(cb);
+    issue_w(0, cb, 0);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();  // this tap's filter (at tap 0: the patch) has landed for every wave; all are done with tap - 1
+      if (tap < 8) issue_w(tap + 1, cb, (tap + 1) & 1);  // lands while this tap is multiplied
+      compute((tap / 3) * PW + tap % 3, tap & 1);
+    }
+  }
+
+  // ---- epilogue straight from the accumulators ----------------------------------------------------------
+  // lane l of acc[i][2 h], acc[i][2 h + 1] holds, for pixel 16 (i & 1) + (l & 15) of image row 2 w + (i >> 1), the eight
+  // consecutive channels 32 h + 8 (l >> 4) .. + 7: one 16-B vector of the output row
+  T* __restrict__ Y = static_cast<T*>(d.y);
+  const T* __restrict__ R = static_cast<const T*>(d.residual);
+  const T* __restrict__ AUX = static_cast<const T*>(d.aux);
+  T* __restrict__ AUXS = static_cast<T*>(d.aux_scaled);
+  const int act = d.act;
+  const bool dot_mode = d.stats && d.stats_mode == O2M_STATS_DOT;
+  const bool stream_out = (size_t)d.B * H * W * Co * 2 >= ((size_t)64 << 20);
+  const int g = lane >> 4, pl = lane & 15;
+  const size_t part = ((size_t)b * tps + tis) * 4 + wave;  // one partial per (tile, wave): 64 pixels of the sample
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    const int en = 32 * h + 8 * g;
+    float esc[8], ebias[8], st[16];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { esc[q] = 1.f; ebias[q] = 0.f; }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) st[q] = 0.f;
+    if (d.out_scale) {
+      const float* sp = d.out_scale + (size_t)b * Co + en;
+      const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 4);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { esc[q] = s0[q]; esc[4 + q] = s1[q]; }
+    }
+    if (d.bias) {
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(d.bias + en), b1 = *reinterpret_cast<const f32x4*>(d.bias + en + 4);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { ebias[q] = b0[q]; ebias[4 + q] = b1[q]; }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int gy = ty0 + 2 * wave + (i >> 1), gx = tx0 + 16 * (i & 1) + pl;
+      const size_t off = ((size_t)(b * H + gy) * W + gx) * Co + en;
+      float o[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { o[r] = acc[i][2 * h][r]; o[4 + r] = acc[i][2 * h + 1][r]; }
+      if (dot_mode) {
+        float xv[8];
+        load8x(AUX + off, xv, stream_out);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) st[q] += o[q] * xv[q];
+        if (AUXS) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) xv[q] *= esc[q];
+          store8x(AUXS + off, xv, stream_out);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) o[q] = o[q] * esc[q] + ebias[q];
+      if (d.stats && !dot_mode) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { st[q] += o[q]; st[8 + q] += o[q] * o[q]; }
+      }
+      act_fwd8(o, act);
+      if (R) {
+        float rv[8];
+        load8(R + off, rv);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] += rv[q];
+      }
+      store8x(Y + off, o, stream_out);
+    }
+    if (d.stats) {
+      // sum over the 16 lanes that share a channel vector (quad swaps, then rotations inside the row of 16): fixed order
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        float v = st[q];
+        v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+        v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+        v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x124, 0xf, 0xf, true));  // row_ror:4
+        v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x128, 0xf, 0xf, true));  // row_ror:8
+        st[q] = v;
+      }
+      if (pl == 0) {
+        float* sp = d.stats + (part * Co + en) * 2;  // [part][channel][sum | sum of squares] (dot mode: [dot | 0])
+#pragma unroll
+        for (int q = 0; q < 8; q += 2)
+          *reinterpret_cast<f32x4*>(sp + 2 * q) = f32x4{st[q], st[8 + q], st[q + 1], st[8 + q + 1]};
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // The same scheme for KS x KS taps (3 or 4), any zero padding < KS, ANY map size (tiles clipped at the edge: loads outside
 // the image are out-of-range DMA offsets, stores and statistics are masked) and any Co % 64 == 0 (64 output channels per
 // block, blockIdx.y = the channel block): the 4 x 4 trunk of the discriminator / style extractor on its odd-sized maps
@@ -1563,6 +1769,19 @@ int launch_halo(const o2m_conv_desc& d, hipStream_t s) {
   return 0;
 }
 
+int launch_halo_w4(const o2m_conv_desc& d, hipStream_t s) {
+  constexpr int lds = 43 * 1024 + 2 * 128 * 128;  // 75 KB: two blocks per CU
+  const long tiles = (long)d.B * (d.H / 8) * (d.W / 32);
+  if (tiles <= 0 || tiles > 0x7fffffffL) return O2M_ERR_BAD_ARG;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_w4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  {
+    LaunchScope timed(s, 2.0 * d.B * d.H * d.W * d.Co * 9.0 * d.Ci, "conv3x3_halo<bf16,8x32x%d>", 128);
+    hipLaunchKernelGGL(conv3x3_halo_w4_kernel, dim3((unsigned)tiles), dim3(256), lds, s, d);
+  }
+  O2M_LAUNCH_CHECK();
+  return 0;
+}
+
 template <int KS>
 int launch_halo_any(const o2m_conv_desc& d, hipStream_t s) {
   constexpr int npix = (8 + KS - 1) * (32 + KS - 1);
@@ -1650,6 +1869,9 @@ int launch_dtype(const o2m_conv_desc& d, hipStream_t s) {
       // patch ingested twice) instead of conv3x3_halo_kernel<128> (25 VGPRs spilled)
       static const int split128 = [] { const char* e = getenv("O2M_HALO128_SPLIT"); return e ? atoi(e) : 0; }();
       if (d.Co == 128 && split128) return launch_halo_any<3>(d, s);
+      // O2M_HALO128_W4=0 (A/B): the 8-wave form of the Co = 128 tile (LDS-staged epilogue, 25 VGPRs spilled)
+      static const int w4 = [] { const char* e = getenv("O2M_HALO128_W4"); return e ? atoi(e) : 1; }();
+      if (d.Co == 128 && w4) return launch_halo_w4(d, s);
       return d.Co == 64 ? launch_halo<64>(d, s) : launch_halo<128>(d, s);
     }
     if (halo_any_ok(d)) return launch_halo_any<4>(d, s);
