@@ -226,7 +226,7 @@ def _separate_decodes(config, device, generator, discriminator, mapping_network,
         gan = _gan_loss(discriminator(ada(generated)))
     style = style_cycle_loss_func(w_trans[-1], style_extractor(generated))
     # (device draw when the mapping network draws there too: core/graphed.py)
-    theta = torch.rand(batch, device=device) if getattr(mapping_network, "device_draws", False) else torch.rand(batch).to(device)
+    theta = torch.rand(batch, device=device) if getattr(mapping_network, "device_draws", False) else ops.host_to_device(torch.rand(batch), device)
     lo, hi = lam["path_loss_jacobian_granularity"]
     h = torch.ones_like(theta).uniform_(lo, hi)
     d1, d2 = (theta + h / 2).clamp(0, 1), (theta - h / 2).clamp(0, 1)
@@ -253,7 +253,7 @@ def _batched_decodes(config, device, generator, discriminator, mapping_network, 
         w_mark.record_stream(torch.cuda.current_stream(device))
     w_trans = mapping_network.get_single_w(batch, blocks, device, 1)
     # (device draw when the mapping network draws there too: core/graphed.py)
-    theta = torch.rand(batch, device=device) if getattr(mapping_network, "device_draws", False) else torch.rand(batch).to(device)
+    theta = torch.rand(batch, device=device) if getattr(mapping_network, "device_draws", False) else ops.host_to_device(torch.rand(batch), device)
     lo, hi = lam["path_loss_jacobian_granularity"]
     h = torch.ones_like(theta).uniform_(lo, hi)
     d1, d2 = (theta + h / 2).clamp(0, 1), (theta - h / 2).clamp(0, 1)

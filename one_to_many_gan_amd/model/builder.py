@@ -48,7 +48,7 @@ class MappingNetwork(nn.Module):
         return self.net(F.normalize(z.float(), dim=1))
 
     def _sample(self, batch_size, device):
-        return self.forward(torch.randn(batch_size, self.d_latent).to(device))
+        return self.forward(ops.host_to_device(torch.randn(batch_size, self.d_latent), device))
 
     def _get_style_vector(self, batch_size, n_gen_blocks, device, *, mix_styles=True):
         if self.device_draws:
@@ -65,7 +65,7 @@ class MappingNetwork(nn.Module):
             # the two latents of a mixed style through the MLP as ONE 2B-row pass (same draws, in the reference's
             # order; every row of the MLP is independent): half the tiny launches of this path
             z = torch.cat((torch.randn(batch_size, self.d_latent), torch.randn(batch_size, self.d_latent)), 0)
-            first, second = self.forward(z.to(device)).split(batch_size, 0)
+            first, second = self.forward(ops.host_to_device(z, device)).split(batch_size, 0)
             return torch.cat((first.expand(cut, -1, -1), second.expand(n_gen_blocks - cut, -1, -1)), 0)
         return self._sample(batch_size, device).expand(n_gen_blocks, -1, -1)
 

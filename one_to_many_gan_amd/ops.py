@@ -444,6 +444,21 @@ _GROUP_STREAM = _os.environ.get("O2M_GROUP_STREAM", "1") == "1"
 _GSTREAM: dict = {}
 
 
+# O2M_ASYNC_H2D=0: host-drawn random numbers reach the device by a blocking copy from pageable memory (A/B)
+_ASYNC_H2D = _os.environ.get("O2M_ASYNC_H2D", "1") == "1"
+
+
+def host_to_device(t: torch.Tensor, device) -> torch.Tensor:
+    """A small host tensor (the reference's CPU-generator draws: z, theta) onto the device WITHOUT making the host wait
+    for the stream: through pinned memory and a non-blocking copy.  ``t.to(device)`` from pageable memory returns only
+    when the copy has run, i.e. when everything queued before it has -- nine such waits per D+G step kept the host from
+    running ahead, and the device starved in every phase made of small kernels (profiles/README.md, round 4)."""
+    device = torch.device(device)
+    if device.type != "cuda" or t.device.type != "cpu" or not _ASYNC_H2D:
+        return t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)
+
+
 def group_stream(device):
     """Second compute stream for an independent sub-graph of a step (None: run it on the current stream)."""
     if not _GROUP_STREAM or device.type != "cuda" or deterministic():
