@@ -702,6 +702,9 @@ long tiles_for(const o2m_conv_desc& d) {
 // then a barrier.  Per phase n the wait leaves regions n+2 .. n+5 in flight, i.e. guarantees n+1.
 // =============================================================================================
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+#ifndef O2M_P8_CHUNK_MAJOR
+#define O2M_P8_CHUNK_MAJOR 0  // (1: chunk-major reduction order -- measured slower, see issue_a; A/B builds: tools/build_variant.sh)
+#endif
 
 // FMT: element format of the MFMA operands.  0 = bf16 (x, w, y bf16: v_mfma_f32_16x16x32_bf16).
 // 1 / 2 = BASELINE config #5, the fp8 path: x is OCP e4m3 (1) or e5m2 (2, gradients), w is e4m3, y / residual are
@@ -804,6 +807,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
   const int CiB = Ci * ES;  // bytes of one pixel's channels = distance between taps kx, kx + 1
   int a_ky[2] = {0, 0}, a_kx[2] = {0, 0}, a_cbB[2] = {0, 0}, a_left[2] = {nk - 1, nk - 1};
   int b_koff[2] = {0, 0};
+  int b_tap[2] = {0, 0};
   const int b_klast = (nk - 1) * 128;
   int a_dst[4], b_dst[4];  // LDS byte offset of fill j inside its operand tile (wave-uniform)
 #pragma unroll
@@ -837,12 +841,26 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
     }
     if (a_left[r] > 0) {
       --a_left[r];
+#if O2M_P8_CHUNK_MAJOR
+      // EXPERIMENT (off): 64-channel chunk outermost, the KH x KW taps inside it, so that a CU cycles through one chunk of
+      // its input patch for all taps while the lines the shifted taps share are still in the XCD's L2 (tap-major: 0.77 hit
+      // rate, 3.8 x the input fetched from the fabric, profiles/r04_z_pmc_igemm_p8.json).  Measured SLOWER: 3 x 3 256 -> 256
+      // at 64 x 64, B = 48 / 32 / 16: 222 / 138 / 70 us against 200 / 128 / 65 us tap-major (profiles/r04_t_p8_order.txt) --
+      // the per-K-tile tap switch (new_tap: offsets of every fill recomputed in the loader half) costs more than the
+      // L2 misses, which the five-phase prefetch distance already hides.
+      if (++a_kx[r] == KW) {
+        a_kx[r] = 0;
+        if (++a_ky[r] == KH) { a_ky[r] = 0; a_cbB[r] += 128; }
+      }
+      new_tap(r);
+#else
       a_cbB[r] += 128;
       if (a_cbB[r] == CiB) {
         a_cbB[r] = 0;
         if (++a_kx[r] == KW) { a_kx[r] = 0; ++a_ky[r]; }
         new_tap(r);
       }
+#endif
     }
   };
   auto issue_b = [&](int r, int buf) {
@@ -852,7 +870,14 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void*)(smem + buf * OPB + b_dst[j]), 16, (int)dwoff[j],
                                                __builtin_amdgcn_readfirstlane(b_koff[r]), 0, 0);
     }
+#if O2M_P8_CHUNK_MAJOR
+    if (b_koff[r] != b_klast) {  // (the filter's K index is tap * Ci + channel: one tap further = + CiB bytes)
+      b_koff[r] += CiB;
+      if (++b_tap[r] == KH * KW) { b_tap[r] = 0; b_koff[r] += 128 - KH * KW * CiB; }
+    }
+#else
     b_koff[r] = min(b_koff[r] + 128, b_klast);
+#endif
   };
 
   // ---- fragments ------------------------------------------------------------------------------------
