@@ -708,15 +708,20 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 // FMT: element format of the MFMA operands.  0 = bf16 (x, w, y bf16: v_mfma_f32_16x16x32_bf16).
 // 1 / 2 = BASELINE config #5, the fp8 path: x is OCP e4m3 (1) or e5m2 (2, gradients), w is e4m3, y / residual are
-// bf16, products on v_mfma_f32_16x16x32_{fp8,bf8}_fp8 with fp32 accumulation and one dequantisation factor
-// (d.deq_scale[0] * d.deq_scale[2]: the {1/scale, amax} pairs of x and w sit at [0..1] and [2..3]) applied to the accumulator.  A 128-B LDS row then
-// holds 128 reduction elements: the same fills and LDS traffic feed twice the MFMA work of the bf16 form.
+// bf16, products on the block-scaled v_mfma_scale_f32_16x16x128_f8f6f4 (unit E8M0 block scales: the scaling is per
+// tensor) with fp32 accumulation and one dequantisation factor (d.deq_scale[0] * d.deq_scale[2]: the {1/scale, amax}
+// pairs of x and w sit at [0..1] and [2..3]) applied to the accumulator.  A 128-B LDS row holds 128 reduction elements
+// and ONE such MFMA (32 cycles, twice the bf16 16x16x32) consumes all of them: the same fills, the same LDS reads and
+// the same MFMA cycles per K-tile as the bf16 form for twice the reduction depth.  (The non-scaled fp8 16x16x32 runs
+// at the bf16 rate on gfx950 -- rounds 2-3 used it and config #5 gained nothing.)  Operand layout, probed on the
+// device (build/probe/mfma_scale_probe.hip): a lane holds 32 bytes of row (l & 15); which reduction elements they are
+// is free as long as both operands agree -- here the two 16-B slots 2 (l >> 4), 2 (l >> 4) + 1 of the row.
 template <int FMT>
 __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_desc d, const int m_begin, const int m_end) {
   using T = unsigned short;               // y / residual element (bf16 in every format)
   constexpr int ES = FMT ? 1 : 2;         // operand element size
   constexpr int KT = 128 / ES;            // reduction elements per K-tile (one 128-B row)
-  constexpr int KS = FMT ? 4 : 2;         // MFMA k-steps (32 elements each) per K-tile
+  constexpr int KS = FMT ? 1 : 2;         // MFMA k-steps per K-tile (bf16: 32 elements each; fp8: all 128 at once)
   constexpr int BM = 256, BN = 256, NT = 512;
   constexpr int OPB = 32768;   // one operand of one K-tile: 256 rows x 128 B
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -881,32 +886,39 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
   };
 
   // ---- fragments ------------------------------------------------------------------------------------
-  // 16x16x32: lane l holds row l & 15 and reduction elements 8 (l >> 4) + 32 ks .. +7 of the K-tile.
-  //   bf16: 16 bytes = chunk (l >> 4) + 4 ks            (ds_read_b128)
-  //   fp8 :  8 bytes = chunk (l >> 5) + 2 ks, half (l >> 4) & 1   (ds_read_b64; conflict-free: the 32 lanes of a
-  //          half-wave touch 16 different slots, two halves each)
+  // lane l holds row l & 15 of a 16-row tile.
+  //   bf16 (16x16x32): reduction elements 8 (l >> 4) + 32 ks .. + 7 = 16-B chunk (l >> 4) + 4 ks    (ds_read_b128)
+  //   fp8 (16x16x128): the 32 bytes of chunks 2 (l >> 4), 2 (l >> 4) + 1, in that order              (2 ds_read_b128;
+  //          the swizzle puts the second at the first's address ^ 16)
   // tile_off(R0 + 16 i + r, c ^ x) = (tile_off(R0 + r, c) ^ ((i & 1) << 7 | x << 4)) + i * 2048  for R0 % 32 == 0
-  using frag_t = std::conditional_t<FMT == 0, bf16x8, long>;
-  constexpr int KSH = FMT ? 5 : 6;  // k-step -> byte XOR: 2 chunks (fp8) or 4 chunks (bf16)
-  const int c0 = FMT ? (lane >> 5) : (lane >> 4), h0 = FMT ? ((lane >> 4) & 1) * 8 : 0;
-  const int fa0 = tile_off(128 * wrow + (lane & 15), c0) + h0;
-  const int fb0 = tile_off(64 * wcol + (lane & 15), c0) + h0 + 2 * OPB;
+  typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+  typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+  using frag_t = std::conditional_t<FMT == 0, bf16x8, i32x8_t>;
+  const int c0 = FMT ? 2 * (lane >> 4) : (lane >> 4);
+  const int fa0 = tile_off(128 * wrow + (lane & 15), c0);
+  const int fb0 = tile_off(64 * wcol + (lane & 15), c0) + 2 * OPB;
+  auto read_frag = [&](const char* base, int off) -> frag_t {
+    if constexpr (FMT == 0) {
+      return *reinterpret_cast<const bf16x8*>(base + off);
+    } else {
+      const i32x4_t lo = *reinterpret_cast<const i32x4_t*>(base + off), hi = *reinterpret_cast<const i32x4_t*>(base + (off ^ 16));
+      return i32x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+  };
   frag_t af[4][KS], b0f[2][KS], b1f[2][KS];
   auto read_a = [&](int buf, int mh) {
     const char* base = smem + buf * OPB + mh * (64 * 128);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks)
-        af[i][ks] = *reinterpret_cast<const frag_t*>(base + ((fa0 ^ (((i & 1) << 7) | (ks << KSH))) + i * 2048));
+      for (int ks = 0; ks < KS; ++ks) af[i][ks] = read_frag(base, (fa0 ^ (((i & 1) << 7) | (ks << 6))) + i * 2048);
   };
   auto read_b = [&](frag_t (&bf)[2][KS], int buf, int nh) {
     const char* base = smem + buf * OPB + nh * (32 * 128);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks)
-        bf[j][ks] = *reinterpret_cast<const frag_t*>(base + ((fb0 ^ (((j & 1) << 7) | (ks << KSH))) + j * 2048));
+      for (int ks = 0; ks < KS; ++ks) bf[j][ks] = read_frag(base, (fb0 ^ (((j & 1) << 7) | (ks << 6))) + j * 2048);
   };
 
   f32x4_t acc[8][4];
@@ -925,9 +937,10 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_p8_kernel(const o2m_conv_de
         for (int j = 0; j < 2; ++j) {
           f32x4_t& c = acc[mh * 4 + i][nh * 2 + j];
           // filter rows as the A operand: a lane's 4 result registers are 4 CHANNELS of one pixel
+          // (cbsz / blgp = element format of the A / B operand: 0 = e4m3, 1 = e5m2; scale bytes 0x7f = 2^0)
           if constexpr (FMT == 0) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][ks], af[i][ks], c, 0, 0, 0);
-          else if constexpr (FMT == 1) c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(bf[j][ks], af[i][ks], c, 0, 0, 0);
-          else c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(bf[j][ks], af[i][ks], c, 0, 0, 0);
+          else c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bf[j][ks], af[i][ks], c, 0, FMT == 2 ? 1 : 0, 0, 0x7f7f7f7f, 0,
+                                                                    0x7f7f7f7f);
         }
     __builtin_amdgcn_s_setprio(0);
   };

@@ -788,6 +788,8 @@ class _ConvFn(torch.autograd.Function):
             H.conv2d_fwd(x, w_f, y, in_scale=s, out_scale=d, bias=bias_p, residual=residual,
                          pad=pad, pad_mode=pad_mode, act=act)
         ctx.prep, ctx.pad, ctx.pad_mode, ctx.act = prep, pad, pad_mode, act
+        # the (mean, rstd) output never carries a gradient: do not let the engine build a zero tensor for it per call
+        ctx.set_materialize_grads(False)
         ctx.link = link if _BLOCK_LINK else None
         ctx.norm_follows = stats_eps is not None
         ctx.counted = prep.note_forward_use(ctx.needs_input_grad[1])
@@ -805,6 +807,8 @@ class _ConvFn(torch.autograd.Function):
         x, y, residual, s, d, weight, bias_p, wv, ws = ctx.saved_tensors
         prep, pad, pad_mode, act = ctx.prep, ctx.pad, ctx.pad_mode, ctx.act
         w_f, w_d, q, _, _ = prep.get()
+        if g is None:  # (set_materialize_grads(False): y itself took no gradient -- nothing flows through this conv)
+            g = torch.zeros_like(y)
         g = g.contiguous()
         B, Hh, Ww, cip = x.shape
         need_x, need_w, need_b = ctx.needs_input_grad[0:3]

@@ -388,7 +388,7 @@ FP8_CONVS = [
 @pytest.mark.parametrize("case", FP8_CONVS, ids=lambda c: "x".join(map(str, c[:7])) + "-" + c[9])
 def test_fp8_conv_matches_torch_on_the_quantised_operands(case):
     """BASELINE config #5: the fp8 form of the phase-pipelined igemm kernel (e4m3 / e5m2 activations x e4m3
-    filters on v_mfma_f32_16x16x32_{fp8,bf8}_fp8, fp32 accumulate, device-side dequantisation factors, bf16 out).
+    filters on the block-scaled v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales), fp32 accumulate, device-side dequantisation factors, bf16 out).
     Checked against torch's fp32 convolution of the SAME quantised operands, so only the summation order and
     the bf16 rounding of y differ (3e-3); the quantisation error itself is what test_hip_parity's fp8 mode bounds."""
     import torch.nn.functional as F

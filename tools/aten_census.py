@@ -31,12 +31,16 @@ class Census(TorchDispatchMode):
                 if f.filename.startswith(ROOT) and "aten_census" not in f.filename:
                     fr = f"{os.path.relpath(f.filename, ROOT)}:{f.lineno} {f.name}"
                     break
+            if fr == "<engine>":
+                node = torch._C._current_autograd_node()
+                if node is not None:
+                    fr = f"<engine: {node.name()}>"
             where[(name, fr)] += 1
         return func(*args, **(kwargs or {}))
 
 with Census():
     tr.step()
 torch.cuda.synchronize()
-for (name, fr), c in where.most_common(70):
+for (name, fr), c in where.most_common(160):
     print(f"{c:5d}  {name:34s} {fr}")
 print("total", sum(where.values()))

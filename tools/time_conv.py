@@ -1,5 +1,5 @@
 """Time ONE conv shape (HIP events around 20 launches, median of 5 rounds).
-Usage: time_conv.py fwd|wgrad B H W Ci Co k pad reflect [more shapes: 8 numbers each]"""
+Usage: time_conv.py fwd|fp8|wgrad B H W Ci Co k pad reflect [more shapes: 8 numbers each]   (fp8: e4m3 x e4m3 forward)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -16,8 +16,13 @@ for k0 in range(0, len(nums), 8):
     y = torch.empty(B, ho, wo, Co, device="cuda", dtype=dt)
     gy = torch.randn(B, ho, wo, Co, device="cuda").to(dt)
     dw = torch.zeros(Co, k, k, Ci, device="cuda")
+    if mode == "fp8":
+        dq = torch.empty(2, 2, device="cuda")
+        x8 = torch.empty(x.shape, dtype=torch.float8_e4m3fn, device="cuda"); w8 = torch.empty(w.shape, dtype=torch.float8_e4m3fn, device="cuda")
+        H.quantize_fp8(x, x8, dq[0]); H.quantize_fp8(w, w8, dq[1])
     def run():
         if mode == "fwd": H.conv2d_fwd(x, w, y, pad=pad, pad_mode=pm, act=H.ACT_NONE)
+        elif mode == "fp8": H.conv2d_fwd(x8, w8, y, pad=pad, pad_mode=pm, act=H.ACT_NONE, deq=dq.view(-1))
         else: H.conv2d_wgrad(x, gy, dw, pad=pad, pad_mode=pm, p8=True)
     for _ in range(5): run()
     ts = []
