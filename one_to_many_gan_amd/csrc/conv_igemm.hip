@@ -1583,6 +1583,202 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_w4_kernel(const o2m_conv_
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// The four-wave form for 64 output channels per block, KS x KS taps (3 or 4), any zero padding < KS and ANY map size
+// (clipped tiles; blockIdx.y = the 64-channel block): replaces conv3x3_halo_kernel<64> and conv_halo_any_kernel<KS> (8-wave
+// blocks, wave tile 64 pixels x 32 channels: 0.75 fragment reads per MFMA, fp32 tile through LDS in four passes).  Wave w
+// owns image rows 2 w, 2 w + 1 of the tile x all 64 channels (64 accumulator VGPRs, 0.5 reads per MFMA); filter rows
+// permuted in LDS as in conv3x3_halo_w4_kernel, epilogue straight from the accumulators with stores and statistics
+// masked at the clipped edge.  59 / 65 KB of LDS (3 x 3 / 4 x 4): two blocks per CU.
+template <int KS>
+__global__ __launch_bounds__(256, 2) void conv_halo_w4c_kernel(const o2m_conv_desc d) {
+  using T = unsigned short;
+  constexpr int CO = 64, TH = 8, TW = 32, PW = TW + KS - 1, NPIX = (TH + KS - 1) * PW;
+  constexpr int PFILLS = (NPIX + 7) / 8, PPW = (PFILLS + 3) / 4;  // fills of 8 pixels; fills per wave
+  constexpr int PATCH_B = PFILLS * 1024;
+  constexpr int WB = CO * 128;  // one filter tap of one chunk: 64 rows x 64 channels
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* patch = smem;
+  char* wbuf = smem + PATCH_B;
+  typedef __attribute__((address_space(3))) void lds_void;
+
+  const int H = d.H, W = d.W, Ci = d.Ci, Co = d.Co, pad = d.pad;
+  const int Ho = H + 2 * pad - KS + 1, Wo = W + 2 * pad - KS + 1;
+  const int K = KS * KS * Ci;
+  const int n0 = blockIdx.y * CO;
+  const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH - 1) / TH, tps = tiles_x * tiles_y;
+  const int tile = xcd_tile_order(blockIdx.x, gridDim.x);
+  const int b = tile / tps, tis = tile - b * tps;
+  const int ty0 = (tis / tiles_x) * TH, tx0 = (tis % tiles_x) * TW;
+  const rsrc_t xr = make_rsrc(d.x, (unsigned)((size_t)d.B * H * W * Ci * 2));
+  const rsrc_t wr = make_rsrc(static_cast<const char*>(d.w) + (size_t)b * d.w_batch_stride * 2, (unsigned)((size_t)Co * K * 2));
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+
+  unsigned poff[PPW];
+#pragma unroll
+  for (int j = 0; j < PPW; ++j) {
+    const int f = 4 * j + wave;
+    const int pp = 8 * f + (lane >> 3);
+    const int c = (lane & 7) ^ ((pp >> 1) & 7);
+    const int py = pp / PW, px = pp - py * PW;
+    const int gy = ty0 + py - pad, gx = tx0 + px - pad;
+    const bool ok = f < PFILLS && pp < NPIX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+    poff[j] = ok ? (unsigned)(((b * H + gy) * W + gx) * Ci + c * 8) * 2u : OOB_OFF;
+  }
+  auto issue_patch = [&](int cb) {
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+      const int f = 4 * j + wave;
+      if (f >= PFILLS) continue;  // wave-uniform
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_void*)(patch + f * 1024), 16, (int)poff[j], cb * 2, 0, 0);
+    }
+  };
+  unsigned woff[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int q = 2 * wave + j;
+    const int pr = 4 * q + (lane >> 4);
+    const int rho = 2 * pr + (((lane & 15) ^ (pr & 15)) >> 3), chk = ((lane & 15) ^ (pr & 15)) & 7;
+    const int n = n0 + 32 * (rho >> 5) + 8 * ((rho >> 2) & 3) + 4 * ((rho >> 4) & 1) + (rho & 3);
+    woff[j] = (unsigned)(n * K + chk * 8) * 2u;
+  }
+  auto issue_w = [&](int tap, int cb, int buf) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_void*)(wbuf + buf * WB + (2 * wave + j) * 1024), 16, (int)woff[j],
+                                               (tap * Ci + cb) * 2, 0, 0);
+  };
+
+  const int c0 = lane >> 4;
+  const int ppb0 = 2 * wave * PW + (lane & 15);
+  const int fb0 = tile_off(lane & 15, c0);
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](const int toff, const int buf) {
+    int aoff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int pp = ppb0 + (toff + (i >> 1) * PW + (i & 1) * 16);
+      aoff[i] = (pp << 7) | ((c0 ^ ((pp >> 1) & 7)) << 4);
+    }
+    const char* wb = wbuf + buf * WB;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 px[4], wf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) px[i] = *reinterpret_cast<const bf16x8*>(patch + (aoff[i] ^ (ks << 6)));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(wb + ((fb0 ^ (((j & 1) << 7) | (ks << 6))) + j * 2048));
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], px[i], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  for (int cb = 0; cb < Ci; cb += 64) {
+    if (cb) __syncthreads();  // every wave is done with the previous chunk's patch and filter buffers
+    issue_patch(cb);
+    issue_w(0, cb, 0);
+#pragma unroll
+    for (int tap = 0; tap < KS * KS; ++tap) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();  // this tap's filter (at tap 0: the patch) has landed for every wave; all are done with tap - 1
+      if (tap + 1 < KS * KS) issue_w(tap + 1, cb, (tap + 1) & 1);
+      compute((tap / KS) * PW + tap % KS, tap & 1);
+    }
+  }
+
+  // ---- epilogue straight from the accumulators (see conv3x3_halo_w4_kernel), masked at the clipped edge -----
+  T* __restrict__ Y = static_cast<T*>(d.y);
+  const T* __restrict__ R = static_cast<const T*>(d.residual);
+  const T* __restrict__ AUX = static_cast<const T*>(d.aux);
+  T* __restrict__ AUXS = static_cast<T*>(d.aux_scaled);
+  const int act = d.act;
+  const bool dot_mode = d.stats && d.stats_mode == O2M_STATS_DOT;
+  const bool stream_out = (size_t)d.B * Ho * Wo * Co * 2 >= ((size_t)64 << 20);
+  const int g = lane >> 4, pl = lane & 15;
+  const size_t part = ((size_t)b * tps + tis) * 4 + wave;  // one partial per (tile, wave): whatever of its 64 pixels exist
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int en = n0 + 32 * h + 8 * g;
+    float esc[8], ebias[8], st[16];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { esc[q] = 1.f; ebias[q] = 0.f; }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) st[q] = 0.f;
+    if (d.out_scale) {
+      const float* sp = d.out_scale + (size_t)b * Co + en;
+      const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 4);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { esc[q] = s0[q]; esc[4 + q] = s1[q]; }
+    }
+    if (d.bias) {
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(d.bias + en), b1 = *reinterpret_cast<const f32x4*>(d.bias + en + 4);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { ebias[q] = b0[q]; ebias[4 + q] = b1[q]; }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int gy = ty0 + 2 * wave + (i >> 1), gx = tx0 + 16 * (i & 1) + pl;
+      if (gy >= Ho || gx >= Wo) continue;  // clipped tile: nothing to store, nothing to count
+      const size_t off = ((size_t)(b * Ho + gy) * Wo + gx) * Co + en;
+      float o[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { o[r] = acc[i][2 * h][r]; o[4 + r] = acc[i][2 * h + 1][r]; }
+      if (dot_mode) {
+        float xv[8];
+        load8x(AUX + off, xv, stream_out);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) st[q] += o[q] * xv[q];
+        if (AUXS) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) xv[q] *= esc[q];
+          store8x(AUXS + off, xv, stream_out);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) o[q] = o[q] * esc[q] + ebias[q];
+      if (d.stats && !dot_mode) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { st[q] += o[q]; st[8 + q] += o[q] * o[q]; }
+      }
+      act_fwd8(o, act);
+      if (R) {
+        float rv[8];
+        load8(R + off, rv);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] += rv[q];
+      }
+      store8x(Y + off, o, stream_out);
+    }
+    if (d.stats) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        float v = st[q];
+        v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+        v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+        v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x124, 0xf, 0xf, true));  // row_ror:4
+        v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x128, 0xf, 0xf, true));  // row_ror:8
+        st[q] = v;
+      }
+      if (pl == 0) {
+        float* sp = d.stats + (part * Co + en) * 2;
+#pragma unroll
+        for (int q = 0; q < 8; q += 2)
+          *reinterpret_cast<f32x4*>(sp + 2 * q) = f32x4{st[q], st[8 + q], st[q + 1], st[8 + q + 1]};
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // The same scheme for KS x KS taps (3 or 4), any zero padding < KS, ANY map size (tiles clipped at the edge: loads outside
 // the image are out-of-range DMA offsets, stores and statistics are masked) and any Co % 64 == 0 (64 output channels per
 // block, blockIdx.y = the channel block): the 4 x 4 trunk of the discriminator / style extractor on its odd-sized maps
@@ -1820,6 +2016,28 @@ int launch_halo_w4(const o2m_conv_desc& d, hipStream_t s) {
   return 0;
 }
 
+// O2M_HALO_W4C (A/B): bit 0 = the 4 x 4 trunk layers, bit 1 = the 3 x 3 Co = 64 layers on the four-wave kernel (default 3);
+// 0 = the 8-wave forms (conv_halo_any_kernel, conv3x3_halo_kernel<64>)
+inline bool halo_w4c_on(int bit) {
+  static const int on = [] { const char* e = getenv("O2M_HALO_W4C"); return e ? atoi(e) : 3; }();
+  return (on >> bit) & 1;
+}
+template <int KS>
+int launch_halo_w4c(const o2m_conv_desc& d, hipStream_t s, const char* name) {
+  constexpr int npix = (8 + KS - 1) * (32 + KS - 1);
+  constexpr int lds = ((npix + 7) / 8) * 1024 + 2 * 64 * 128;
+  const int Ho = d.H + 2 * d.pad - KS + 1, Wo = d.W + 2 * d.pad - KS + 1;
+  const long tiles = (long)d.B * ((Ho + 7) / 8) * ((Wo + 31) / 32);
+  if (tiles <= 0 || tiles > 0x7fffffffL || d.Co % 64 || d.Co / 64 > 65535) return O2M_ERR_BAD_ARG;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_w4c_kernel<KS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  {
+    LaunchScope timed(s, 2.0 * d.B * Ho * Wo * d.Co * (double)(KS * KS) * d.Ci, "%s", name);
+    hipLaunchKernelGGL(conv_halo_w4c_kernel<KS>, dim3((unsigned)tiles, (unsigned)(d.Co / 64)), dim3(256), lds, s, d);
+  }
+  O2M_LAUNCH_CHECK();
+  return 0;
+}
+
 template <int KS>
 int launch_halo_any(const o2m_conv_desc& d, hipStream_t s) {
   constexpr int npix = (8 + KS - 1) * (32 + KS - 1);
@@ -1910,9 +2128,10 @@ int launch_dtype(const o2m_conv_desc& d, hipStream_t s) {
       // O2M_HALO128_W4=0 (A/B): the 8-wave form of the Co = 128 tile (LDS-staged epilogue, 25 VGPRs spilled)
       static const int w4 = [] { const char* e = getenv("O2M_HALO128_W4"); return e ? atoi(e) : 1; }();
       if (d.Co == 128 && w4) return launch_halo_w4(d, s);
+      if (d.Co == 64 && halo_w4c_on(1)) return launch_halo_w4c<3>(d, s, "conv3x3_halo<bf16,8x32x64>");
       return d.Co == 64 ? launch_halo<64>(d, s) : launch_halo<128>(d, s);
     }
-    if (halo_any_ok(d)) return launch_halo_any<4>(d, s);
+    if (halo_any_ok(d)) return halo_w4c_on(0) ? launch_halo_w4c<4>(d, s, "conv_halo<bf16,4x4,8x32x64>") : launch_halo_any<4>(d, s);
   }
   // big 8-wave tiles when they still give every CU a block; otherwise the 4-wave 128-wide
   // tiles (small-M layers of the discriminator) so the chip stays filled
