@@ -165,14 +165,15 @@ def kernel_profile(trainer, precision, steps=3):
     # stream (every kernel alone on the chip: this is what a rocprofv3 table of a single-stream run shows too,
     # profiles/README.md); the durations of the same kernels as the timed region runs them are reported beside it
     # (`in_timed_region`).
-    multi = getattr(o2m_ops, "_WGRAD_STREAM", False) or getattr(o2m_ops, "_GROUP_STREAM", False)
+    multi = (getattr(o2m_ops, "_WGRAD_STREAM", False) or getattr(o2m_ops, "_GROUP_STREAM", False)
+             or getattr(o2m_ops, "_D_OVERLAP", False))
     in_step = timed_steps() if multi else None
-    saved = (o2m_ops._WGRAD_STREAM, o2m_ops._GROUP_STREAM)
-    o2m_ops._WGRAD_STREAM = o2m_ops._GROUP_STREAM = False
+    saved = (o2m_ops._WGRAD_STREAM, o2m_ops._GROUP_STREAM, o2m_ops._D_OVERLAP)
+    o2m_ops._WGRAD_STREAM = o2m_ops._GROUP_STREAM = o2m_ops._D_OVERLAP = False
     try:
         agg = timed_steps()
     finally:
-        o2m_ops._WGRAD_STREAM, o2m_ops._GROUP_STREAM = saved
+        o2m_ops._WGRAD_STREAM, o2m_ops._GROUP_STREAM, o2m_ops._D_OVERLAP = saved
     if not agg:
         return None
     total_conv_s = sum(a[1] for a in agg.values())

@@ -149,6 +149,13 @@ def _l1(a, b):
     return ops.l1_sum(ops.to_internal(a), ops.to_internal(b)) / a.numel()
 
 
+def _await_discriminator(device, discriminator):
+    """The generator step's first use of the discriminator: behind the discriminator step's optimiser (which may still
+    be running on its own stream), then its filter forms."""
+    ops.d_step_wait(device, "done")
+    ops.prepare_network(discriminator)
+
+
 def _gan_loss(scores):
     """((D(G(x)) - 1)^2).mean() (training.py:202) through the fused patch-map reduction."""
     sums = ops.lsgan_sums(ops.to_internal(scores), scores.shape[0], 1.0, 1.0)
@@ -172,10 +179,27 @@ def discriminator_step(config, device, discriminator, generator, mapping_network
                        shoemark_iter: Iterator[torch.Tensor], image_buffer, ada, ada_p):
     """One discriminator update; returns ``(loss, (real_confidence, fake_confidence))``
     exactly like the reference (training.py:71-128)."""
+    st = ops.d_step_stream(device) if torch.device(device).type == "cuda" else None
+    if st is None:
+        return _discriminator_step(config, device, discriminator, generator, mapping_network, discriminator_optimiser,
+                                   shoeprint_iter, shoemark_iter, image_buffer, ada, ada_p)
+    # on its own stream, behind everything queued so far (the previous generator step's optimisers included): the
+    # generator step that follows runs its generator-side passes beside this step's backward (ops.d_step_stream)
+    st.wait_stream(torch.cuda.current_stream(device))
+    with torch.cuda.stream(st):
+        out = _discriminator_step(config, device, discriminator, generator, mapping_network, discriminator_optimiser,
+                                  shoeprint_iter, shoemark_iter, image_buffer, ada, ada_p)
+        ops.d_step_mark(device, "done")
+    return out
+
+
+def _discriminator_step(config, device, discriminator, generator, mapping_network,
+                        discriminator_optimiser, shoeprint_iter, shoemark_iter, image_buffer, ada, ada_p):
     batch = config["training"]["batch_size"]
     discriminator_optimiser.zero_grad()
     for net in (generator, discriminator):
         ops.prepare_network(net)  # every stale filter of a network in one launch
+    ops.d_step_mark(device, "prep")  # (the generator's filter forms are shared with the generator step)
 
     shoeprints = next(shoeprint_iter).to(device)
     with torch.no_grad():
@@ -222,6 +246,7 @@ def _separate_decodes(config, device, generator, discriminator, mapping_network,
     idt = _l1(generator.decode(z_mark, w_mark.expand(blocks, *w_mark.shape)), shoemarks)
     w_trans = mapping_network.get_single_w(batch, blocks, device, 1)
     generated = generator.decode(z_print, w_trans)
+    _await_discriminator(device, discriminator)
     with _frozen(discriminator):
         gan = _gan_loss(discriminator(ada(generated)))
     style = style_cycle_loss_func(w_trans[-1], style_extractor(generated))
@@ -296,6 +321,7 @@ def _batched_decodes(config, device, generator, discriminator, mapping_network, 
         gen_t.record_stream(side)
         with torch.cuda.stream(side):
             style_of_generated = style_extractor(generated)
+    _await_discriminator(device, discriminator)
     with _frozen(discriminator):
         gan = _gan_loss(discriminator(ada(generated)))
 
@@ -320,9 +346,13 @@ def generator_step(config, device, generator, discriminator, mapping_network, st
     batch = config["training"]["batch_size"]
     lam = config["optimisation"]
     blocks = generator.n_style_blocks
+    # a discriminator step running on its own stream (ops.d_step_stream) has rebuilt the generator's filter forms: wait
+    # for those; the discriminator itself (its optimiser still running there) is waited for and prepared where the
+    # adversarial term needs it (_await_discriminator)
+    ops.d_step_wait(device, "prep")
     for opt in (generator_optimiser, mapping_network_optimiser, style_extractor_optimiser):
         opt.zero_grad()
-    for net in (generator, discriminator, style_extractor):
+    for net in (generator, style_extractor):
         ops.prepare_network(net)  # every stale filter of a network in one launch
 
     shoeprints = next(shoeprint_iter).to(device)

@@ -459,6 +459,58 @@ def host_to_device(t: torch.Tensor, device) -> torch.Tensor:
     return t.pin_memory().to(device, non_blocking=True)
 
 
+# O2M_D_OVERLAP=0: discriminator_step on the caller's stream (the generator step's forward then waits for all of it)
+_D_OVERLAP = _os.environ.get("O2M_D_OVERLAP", "1") == "1"
+_DSTREAM: dict = {}
+_D_EVENTS: dict = {}   # device -> {"prep": event behind the step's weight preparation, "done": event behind the whole step}
+
+
+def d_step_stream(device):
+    """Stream of ``discriminator_step`` (None: the current one).  The generator step that follows needs the updated
+    discriminator only for its adversarial term, AFTER its own encoder and decoder passes: with the discriminator step
+    on a stream of its own, those passes share the chip with the discriminator's backward and optimiser (a batch-16 /
+    32 sequence of small launches that leaves CUs idle) instead of queuing behind them.  ``generator_step`` waits for
+    ``d_step_event(device, "done")`` before it touches the discriminator.  Not under graph capture, not in
+    deterministic mode (one stream there), not on CPU tensors."""
+    device = torch.device(device)
+    if not _D_OVERLAP or device.type != "cuda" or deterministic() or torch.cuda.is_current_stream_capturing():
+        return None
+    st = _DSTREAM.get(device)
+    if st is None:
+        st = _DSTREAM[device] = torch.cuda.Stream(device=device)
+    return st
+
+
+def _on_d_stream(device) -> bool:
+    st = _DSTREAM.get(torch.device(device)) if torch.device(device).type == "cuda" else None
+    return st is not None and torch.cuda.current_stream(device) == st
+
+
+def d_step_mark(device, which: str):
+    """Record the discriminator step's ``prep`` / ``done`` event on the current stream -- only when that is the
+    discriminator step's own stream (a step on the caller's stream is ordered by the stream itself: events dropped)."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        return
+    if not _on_d_stream(device):
+        _D_EVENTS.pop(device, None)
+        return
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(device))
+    _D_EVENTS.setdefault(device, {})[which] = ev
+
+
+def d_step_wait(device, which: str):
+    """Order the current stream behind the last discriminator step's ``prep`` / ``done`` event (no-op when that step ran
+    on the caller's stream or none has run)."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        return
+    ev = _D_EVENTS.get(device, {}).get(which)
+    if ev is not None and not torch.cuda.is_current_stream_capturing():
+        torch.cuda.current_stream(device).wait_event(ev)
+
+
 def group_stream(device):
     """Second compute stream for an independent sub-graph of a step (None: run it on the current stream)."""
     if not _GROUP_STREAM or device.type != "cuda" or deterministic():
@@ -609,23 +661,30 @@ class _ZeroPool:
     def __init__(self):
         self.buf, self.used, self.dirty = {}, {}, {}
 
+    @staticmethod
+    def _key(device):
+        # the discriminator step may run on its own stream beside the next generator step's forward (d_step_stream):
+        # its backward's slices must not be cleared by the generator step's zero_grad -- one pool per side
+        return (device, _on_d_stream(device))
+
     def take(self, n: int, device) -> torch.Tensor:
-        buf = self.buf.get(device)
+        key = self._key(device)
+        buf = self.buf.get(key)
         if buf is None:
-            buf = self.buf[device] = torch.zeros(self.CAPACITY, dtype=torch.float32, device=device)
-            self.used[device] = 0
-        off = self.used[device]
+            buf = self.buf[key] = torch.zeros(self.CAPACITY, dtype=torch.float32, device=device)
+            self.used[key] = 0
+        off = self.used[key]
         n4 = (n + 3) // 4 * 4  # 16-B aligned slices
         if off + n4 > self.CAPACITY:
             return torch.zeros(n, dtype=torch.float32, device=device)
-        self.used[device] = off + n4
+        self.used[key] = off + n4
         return buf[off: off + n]
 
     def reset(self):
-        for device, buf in self.buf.items():
-            if self.used[device]:
-                buf[: self.used[device]].zero_()
-                self.used[device] = 0
+        for key, buf in self.buf.items():
+            if self.used[key] and key == self._key(key[0]):  # (the pool of the side that is resetting)
+                buf[: self.used[key]].zero_()
+                self.used[key] = 0
 
 
 ZERO_POOL = _ZeroPool()
