@@ -91,6 +91,17 @@ class Trainer:
         torch.manual_seed(t["random_seed"] + 1 + seed_offset)  # z / theta / h streams differ per rank
 
     def step(self):
+        # O2M_MAIN_PRIO=1 (experiment): the step's main stream is a high-priority stream, so that its kernels are
+        # dispatched ahead of the side streams' (weight gradient, discriminator step, extraction group) when CUs free up
+        if os.environ.get("O2M_MAIN_PRIO", "0") == "1" and self.device.type == "cuda":
+            if getattr(self, "_prio", None) is None:
+                self._prio = torch.cuda.Stream(device=self.device, priority=-1)
+                self._prio.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self._prio):
+                return self._step()
+        return self._step()
+
+    def _step(self):
         """The loop body of train.py:204-251."""
         # The benchmark workload holds the augmentation at p = 0 (SURVEY.md section 8d; the CPU oracle
         # has no transforms): the ADAp controller still runs inside discriminator_step, its output

@@ -517,7 +517,7 @@ def group_stream(device):
         return None
     st = _GSTREAM.get(device)
     if st is None:
-        st = _GSTREAM[device] = torch.cuda.Stream(device=device)
+        st = _GSTREAM[device] = torch.cuda.Stream(device=device, priority=int(_os.environ.get("O2M_PRIO_GROUP", "0")))
     return st
 
 
