@@ -233,6 +233,11 @@ _BATCH_DECODES = os.environ.get("O2M_BATCH_DECODES", "1") == "1"
 # O2M_SIDE_STYLE=0: both style-extractor passes of generator_step on the main stream (A/B of running them beside the
 # encoder / the discriminator on the second stream)
 _SIDE_STYLE = os.environ.get("O2M_SIDE_STYLE", "1") == "1"
+# O2M_SIDE_MAPPING=1 (experiment, off): generator_step's mapping-network passes on a stream of their own.  Measured
+# SLOWER: a chain of ~60 dependent 4-us launches beside kernels that keep every CU busy advances one link per freed CU --
+# 35.6-35.8 vs 34.4 ms per step, 38.3 with eight hardware queues (GPU_MAX_HW_QUEUES=8), 42.4 on a high-priority stream
+# (O2M_PRIO_MAP=-1), the decode group waiting for it all the while (profiles/r04_ab_mapping_stream.txt)
+_SIDE_MAPPING = os.environ.get("O2M_SIDE_MAPPING", "0") == "1"
 
 
 def _separate_decodes(config, device, generator, discriminator, mapping_network, style_extractor, ada, latents,
@@ -261,7 +266,7 @@ def _separate_decodes(config, device, generator, discriminator, mapping_network,
 
 
 def _batched_decodes(config, device, generator, discriminator, mapping_network, style_extractor, ada, t_lat,
-                     shoeprints, shoemarks, w_mark=None, mark_ready=None):
+                     shoeprints, shoemarks, w_mark=None, mark_ready=None, step_start=None):
     """The same five decoder passes as TWO: the three decodes (training.py:171-199) as one 3B batch and the two
     feature extractions (training.py:226-231) as one 2B batch.  The decoder is per-sample throughout (style
     modulation / demodulation per sample, no normalisation), so every sample's result is that of its separate
@@ -270,27 +275,54 @@ def _batched_decodes(config, device, generator, discriminator, mapping_network, 
     batch, lam, blocks = config["training"]["batch_size"], config["optimisation"], generator.n_style_blocks
     # Every style vector first, in the reference's draw order (builder.py:115-128, training.py:214-223:
     # get_single_w(1) -> theta -> h -> get_two_w; get_single_w(0) and the style extractor draw nothing) ...
-    w_zero = mapping_network.get_single_w(batch, blocks, device, 0)
+    side = ops.group_stream(device)
+
+    def draw_styles():
+        w_zero = mapping_network.get_single_w(batch, blocks, device, 0)
+        w_trans = mapping_network.get_single_w(batch, blocks, device, 1)
+        # (device draw when the mapping network draws there too: core/graphed.py)
+        theta = (torch.rand(batch, device=device) if getattr(mapping_network, "device_draws", False)
+                 else ops.host_to_device(torch.rand(batch), device))
+        lo, hi = lam["path_loss_jacobian_granularity"]
+        h = torch.ones_like(theta).uniform_(lo, hi)
+        d1, d2 = (theta + h / 2).clamp(0, 1), (theta - h / 2).clamp(0, 1)
+        w1, w2 = mapping_network.get_two_w(batch, blocks, device, (d1, d2))
+        return w_zero, w_trans, h, w1, w2
+
+    mst = ops.mapping_stream(device) if _SIDE_MAPPING else None
+    if mst is not None:
+        # the mapping network's ~60 tiny launches (and, in backward, its ~100) on a stream of their own: beside the
+        # encoder's forward, and in backward beside the encoder's backward instead of in front of it on the main stream
+        # (the host draws, and therefore the random numbers, are in the same order).  NOT the group stream: there they
+        # queue behind the style extractor's pass and the decode group waits for them (+1.6 ms)
+        main0 = torch.cuda.current_stream(device)
+        if step_start is not None:
+            mst.wait_event(step_start)  # (behind the previous step's optimisers, NOT behind the encoder queued since)
+        else:
+            mst.wait_stream(main0)
+        with torch.cuda.stream(mst):
+            w_zero, w_trans, h, w1, w2 = draw_styles()
+            styles_ready = torch.cuda.Event()
+            styles_ready.record(mst)
+        main0.wait_event(styles_ready)
+        for t in (w_zero, w_trans, h, w1, w2):
+            t.record_stream(main0)
+            if side is not None:
+                t.record_stream(side)
+    else:
+        w_zero, w_trans, h, w1, w2 = draw_styles()
     if w_mark is None:
         w_mark = style_extractor(shoemarks)
     else:  # computed on the second stream beside the encoder (generator_step): order the main stream behind it
         torch.cuda.current_stream(device).wait_event(mark_ready)
         w_mark.record_stream(torch.cuda.current_stream(device))
-    w_trans = mapping_network.get_single_w(batch, blocks, device, 1)
-    # (device draw when the mapping network draws there too: core/graphed.py)
-    theta = torch.rand(batch, device=device) if getattr(mapping_network, "device_draws", False) else ops.host_to_device(torch.rand(batch), device)
-    lo, hi = lam["path_loss_jacobian_granularity"]
-    h = torch.ones_like(theta).uniform_(lo, hi)
-    d1, d2 = (theta + h / 2).clamp(0, 1), (theta - h / 2).clamp(0, 1)
-    w1, w2 = mapping_network.get_two_w(batch, blocks, device, (d1, d2))
 
     # The extraction group depends on the latents and the style vectors only: it runs on a second stream, so its
     # HBM-bound kernels share the chip with the decode group's MFMA kernels (and the reverse) in forward AND in
     # backward (autograd runs a node's backward on the stream of its forward and orders the streams itself).
-    side = ops.group_stream(device)
-    w_ext = torch.cat([w1, w2], dim=1)
 
     def extraction_group():
+        w_ext = torch.cat([w1, w2], dim=1)
         # the path-loss term of every feature map is taken as the map passes (ops.halves_sq_tap)
         inv_h2 = (1.0 / (h.float() ** 2)).contiguous()
         feats = generator._decode(ops.batch_gather(t_lat, batch, (0, 0)), w_ext, collect=True, internal=True,
@@ -311,7 +343,7 @@ def _batched_decodes(config, device, generator, discriminator, mapping_network, 
     rec = ops.l1_sum(rec_t, ops.to_internal(shoeprints)) / n_img
     idt = ops.l1_sum(idt_t, ops.to_internal(shoemarks)) / n_img
     generated = ops.to_public(gen_t, shoeprints.shape[1])
-    style_of_generated = None
+    style_of_generated = style = None
     if side is not None and _SIDE_STYLE:
         # the style extractor's pass over the generated images beside the discriminator's (independent networks,
         # one input): on the second stream, behind the extraction group
@@ -321,6 +353,10 @@ def _batched_decodes(config, device, generator, discriminator, mapping_network, 
         gen_t.record_stream(side)
         with torch.cuda.stream(side):
             style_of_generated = style_extractor(generated)
+            # its loss term there too: the ~15 tiny kernels of the cosine / MSE arithmetic (and, in backward, their ~40)
+            # run beside the discriminator instead of in the stretch between the forward and backward passes where
+            # nothing else can
+            style = style_cycle_loss_func(w_trans[-1], style_of_generated)
     _await_discriminator(device, discriminator)
     with _frozen(discriminator):
         gan = _gan_loss(discriminator(ada(generated)))
@@ -333,7 +369,10 @@ def _batched_decodes(config, device, generator, discriminator, mapping_network, 
         main.wait_stream(side)
         path.record_stream(main)
         style_of_generated.record_stream(main)
-    style = style_cycle_loss_func(w_trans[-1], style_of_generated)
+        if style is not None:
+            style.record_stream(main)
+    if style is None:
+        style = style_cycle_loss_func(w_trans[-1], style_of_generated)
     return rec, idt, gan, style, path
 
 
@@ -360,7 +399,10 @@ def generator_step(config, device, generator, discriminator, mapping_network, st
 
     # the style of the real shoemarks does not depend on the generator: its pass runs on the second stream beside
     # the encoder (and its backward beside whatever the main stream does then)
-    w_mark = mark_ready = None
+    w_mark = mark_ready = step_start = None
+    if torch.device(device).type == "cuda" and not torch.cuda.is_current_stream_capturing():
+        step_start = torch.cuda.Event()
+        step_start.record(torch.cuda.current_stream(device))
     side = ops.group_stream(device) if (_BATCH_DECODES and _SIDE_STYLE) else None
     if side is not None:
         side.wait_stream(torch.cuda.current_stream(device))
@@ -381,7 +423,8 @@ def generator_step(config, device, generator, discriminator, mapping_network, st
                                                        style_extractor, ada, latents, shoeprints, shoemarks)
     else:
         rec, idt, gan, style, path = _batched_decodes(config, device, generator, discriminator, mapping_network,
-                                                      style_extractor, ada, t_lat, shoeprints, shoemarks, w_mark, mark_ready)
+                                                      style_extractor, ada, t_lat, shoeprints, shoemarks, w_mark, mark_ready,
+                                                      step_start)
 
     total = ops.weighted_sum((gan, idt, rec, kl, path, style),
                              (1.0, lam["identity_loss_lambda"], lam["reconstruction_loss_lambda"], lam["kl_loss_lambda"],

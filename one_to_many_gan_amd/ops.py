@@ -521,6 +521,21 @@ def group_stream(device):
     return st
 
 
+_MSTREAM: dict = {}
+
+
+def mapping_stream(device):
+    """A stream of its own for generator_step's mapping-network passes (tiny launches, forward and backward): on the
+    group stream they would queue behind the style extractor's pass and hold up the decode group that waits for them
+    (measured: +1.6 ms)."""
+    if group_stream(device) is None:
+        return None
+    st = _MSTREAM.get(device)
+    if st is None:
+        st = _MSTREAM[device] = torch.cuda.Stream(device=device, priority=int(_os.environ.get("O2M_PRIO_MAP", "0")))
+    return st
+
+
 def _side_stream(device):
     if not _SIDE_STREAM or device.type != "cuda":
         return None
@@ -642,6 +657,8 @@ def _finalize_weight_grads():
         torch.cuda.current_stream(dev).wait_stream(wst)
     for dev, gst in _GSTREAM.items():  # style gradients accumulated by a group that ran on its own stream
         torch.cuda.current_stream(dev).wait_stream(gst)
+    for dev, mst in _MSTREAM.items():  # (the mapping network's backward: its parameters' gradients)
+        torch.cuda.current_stream(dev).wait_stream(mst)
     live = [prep for prep in pend if prep.pending]
     if len(live) > 1 and _BATCHED_FINALIZE and _finalize_batched(live):
         return
