@@ -187,6 +187,12 @@ int o2m_conv2d_dots_finalize(const float* partial, float* dots, int32_t B, int32
 int o2m_amax(const void* x, float* amax, int64_t n, int32_t dtype, void* stream);
 int o2m_quantize_fp8(const void* x, const float* amax, void* y, float* deq, int64_t n, int32_t dtype,
                      int32_t fmt, void* stream);
+/* Delayed scaling: ONE pass.  The scale comes from `amax_prev` -- the O2M_AMAX_PARTIALS partial maxima of the tensor the
+ * same call site quantised last time (written by o2m_amax or by this function) -- and the partial maxima of THIS tensor go
+ * to `amax_next` (all O2M_AMAX_PARTIALS slots written; a different buffer) for the next call.  Values beyond the previous
+ * amax saturate.  deq[0] = 1 / scale, deq[1] = the amax the scale was made from. */
+int o2m_quantize_fp8_delayed(const void* x, const float* amax_prev, void* y, float* deq, float* amax_next, int64_t n,
+                             int32_t dtype, int32_t fmt, void* stream);
 
 /* Kernel-side forms of one equalised-LR filter (layers.py:12-24: W*c is recomputed on every
  * forward).  w is the parameter, fp32 [Co][Ci][KK] (KK = KH*KW).  Written:

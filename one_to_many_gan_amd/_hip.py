@@ -33,7 +33,7 @@ ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 PAD_ZERO, PAD_REFLECT = 0, 1
 RED_L1, RED_SQ, RED_MOM = 0, 1, 2
 STATS_MOMENTS, STATS_DOT = 0, 1
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -84,6 +84,7 @@ SIGNATURES = {
     "o2m_conv2d_dots_finalize": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "o2m_amax": (_i32, [_vp, _vp, _i64, _i32, _vp]),
     "o2m_quantize_fp8": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "o2m_quantize_fp8_delayed": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "o2m_instnorm_finalize": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),
     "o2m_conv2d_wgrad": (_i32, [C.POINTER(WgradDesc), _vp]),
     "o2m_conv2d_wgrad_slab_floats": (C.c_size_t, [C.POINTER(WgradDesc)]),
@@ -286,6 +287,33 @@ def quantize_fp8(x, y, deq):
     ws = _AMAX_WS.get(x.device, AMAX_PARTIALS)
     ops().amax(x, ws)
     ops().quantize_fp8(x, ws, y, deq)
+
+
+class Fp8Site:
+    """Delayed-scaling state of ONE quantisation call site (a layer's activations or gradients, per stream): two amax
+    workspaces used alternately -- the scale of a call comes from the tensor the site quantised last time."""
+
+    __slots__ = ("bufs", "cur")
+
+    def __init__(self):
+        self.bufs, self.cur = None, -1  # cur: index of the workspace holding the LAST tensor's partial maxima
+
+
+def quantize_fp8_site(x, y, deq, site: Fp8Site):
+    """``quantize_fp8`` with delayed scaling: the first call of a site runs the two-pass form (and keeps its partial
+    maxima); every later call is ONE pass -- scale from the previous call's maxima, this tensor's maxima recorded for
+    the next (o2m_quantize_fp8_delayed).  Values that outgrow the previous amax saturate."""
+    if site.bufs is None or site.bufs[0].device != x.device:
+        site.bufs = [torch.zeros(AMAX_PARTIALS, dtype=torch.float32, device=x.device) for _ in range(2)]
+        site.cur = -1
+    if site.cur < 0:
+        ops().amax(x, site.bufs[0])
+        ops().quantize_fp8(x, site.bufs[0], y, deq)
+        site.cur = 0
+        return
+    prev, nxt = site.bufs[site.cur], site.bufs[1 - site.cur]
+    ops().quantize_fp8_delayed(x, prev, y, deq, nxt)
+    site.cur = 1 - site.cur
 
 
 def conv2d_stats_chunks(x, w, y, *, pad, stride=1):

@@ -1105,10 +1105,12 @@ __global__ __launch_bounds__(NT) void amax_kernel(const T* __restrict__ x, float
 }
 
 // y = fp8(x * scale), 8 values (one 8-byte store) per thread; thread 0 also publishes 1 / scale
-template <typename T, bool E5M2>
+// TRACK (delayed scaling): `amax` holds the partial maxima of the tensor this site quantised LAST time; the maxima of THIS
+// tensor go to `next` (one per block, the rest zeroed by block 0) for the next call -- one pass over x instead of two.
+template <typename T, bool E5M2, bool TRACK = false>
 __global__ __launch_bounds__(NT) void quantize_fp8_kernel(const T* __restrict__ x, const float* __restrict__ amax,
                                                           unsigned long long* __restrict__ y, float* __restrict__ deq,
-                                                          long nvec) {
+                                                          long nvec, float* __restrict__ next = nullptr) {
   const float fmt_max = E5M2 ? 57344.f : 448.f;
   // every block reduces the O2M_AMAX_PARTIALS partial maxima (4 KB out of L2) to the tensor's amax
   __shared__ float red[NT / 64];
@@ -1126,9 +1128,14 @@ __global__ __launch_bounds__(NT) void quantize_fp8_kernel(const T* __restrict__ 
     deq[0] = 1.f / scale;
     deq[1] = m;  // the tensor's amax, for the caller's records (delayed scaling, tests)
   }
+  float seen = 0.f;
   for (long v = (long)blockIdx.x * NT + threadIdx.x; v < nvec; v += (long)gridDim.x * NT) {
     float f[8];
     load8(x + v * 8, f);
+    if (TRACK) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) seen = fmaxf(seen, fabsf(f[i]));
+    }
     // v_cvt_pk_{fp8,bf8}_f32: two floats -> two bytes (RNE), into the low / high half of a dword
     float c[8];
 #pragma unroll
@@ -1146,6 +1153,21 @@ __global__ __launch_bounds__(NT) void quantize_fp8_kernel(const T* __restrict__ 
       w[1] = __builtin_amdgcn_cvt_pk_fp8_f32(c[6], c[7], w[1], true);
     }
     y[v] = (unsigned long long)w[0] | ((unsigned long long)w[1] << 32);
+  }
+  if (TRACK) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) seen = fmaxf(seen, __shfl_xor(seen, off, 64));
+    __syncthreads();  // (red is read above by every thread)
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = seen;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float mm = red[0];
+#pragma unroll
+      for (int i = 1; i < NT / 64; ++i) mm = fmaxf(mm, red[i]);
+      next[blockIdx.x] = mm;
+    }
+    if (blockIdx.x == 0)
+      for (int i = gridDim.x + threadIdx.x; i < O2M_AMAX_PARTIALS; i += NT) next[i] = 0.f;
   }
 }
 
@@ -1215,7 +1237,7 @@ void close(int slot, hipStream_t s) {
 
 extern "C" {
 
-int o2m_abi_version(void) { return 21; }
+int o2m_abi_version(void) { return 22; }
 
 int32_t o2m_launch_timing(int32_t enable) {
   std::lock_guard<std::mutex> lock(o2m_timing::g_mu);
@@ -1273,6 +1295,24 @@ int o2m_quantize_fp8(const void* x, const float* amax, void* y, float* deq, int6
   } else {
     DISPATCH_T(dtype, hipLaunchKernelGGL((quantize_fp8_kernel<T, true>), dim3(grid_for(nvec)), dim3(NT), 0, st,
                                          (const T*)x, amax, (unsigned long long*)y, deq, nvec));
+  }
+  O2M_LAUNCH_CHECK();
+  return 0;
+}
+
+int o2m_quantize_fp8_delayed(const void* x, const float* amax_prev, void* y, float* deq, float* amax_next, int64_t n,
+                             int32_t dtype, int32_t fmt, void* stream) {
+  if (!x || !amax_prev || !y || !deq || !amax_next || amax_prev == amax_next || n <= 0 || (n & 7)) return O2M_ERR_BAD_ARG;
+  if (fmt != O2M_FP8_E4M3 && fmt != O2M_BF8_E5M2) return O2M_ERR_BAD_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const long nvec = n / 8;
+  const unsigned grid = (unsigned)std::min<long>(grid_for(nvec), O2M_AMAX_PARTIALS);  // one partial per block
+  if (fmt == O2M_FP8_E4M3) {
+    DISPATCH_T(dtype, hipLaunchKernelGGL((quantize_fp8_kernel<T, false, true>), dim3(grid), dim3(NT), 0, st, (const T*)x,
+                                         amax_prev, (unsigned long long*)y, deq, nvec, amax_next));
+  } else {
+    DISPATCH_T(dtype, hipLaunchKernelGGL((quantize_fp8_kernel<T, true, true>), dim3(grid), dim3(NT), 0, st, (const T*)x,
+                                         amax_prev, (unsigned long long*)y, deq, nvec, amax_next));
   }
   O2M_LAUNCH_CHECK();
   return 0;

@@ -329,6 +329,19 @@ void quantize_fp8(const Tensor& x, const Tensor& amax_t, Tensor& y, Tensor& deq)
   O2M_CALL(op, x, o2m_quantize_fp8(ptr(x), ptr<float>(amax_t), ptr(y), ptr<float>(deq), x.numel(), dt_x, fmt, stream));
 }
 
+void quantize_fp8_delayed(const Tensor& x, const Tensor& amax_prev, Tensor& y, Tensor& deq, Tensor& amax_next) {
+  const char* op = "o2m::quantize_fp8_delayed";
+  chk(x, op, "x"); chk_f32(amax_prev, op, "amax_prev"); chk(y, op, "y"); chk_f32(deq, op, "deq"); chk_f32(amax_next, op, "amax_next");
+  TORCH_CHECK(is_fp8(y) && y.numel() == x.numel() && x.numel() % 8 == 0, op, ": y is an fp8 tensor of x's size (multiple of 8)");
+  TORCH_CHECK(amax_prev.numel() >= O2M_AMAX_PARTIALS && amax_next.numel() >= O2M_AMAX_PARTIALS && deq.numel() >= 2 &&
+                  amax_prev.data_ptr() != amax_next.data_ptr(),
+              op, ": two different amax workspaces of ", O2M_AMAX_PARTIALS, " floats, deq of 2 ({1 / scale, amax})");
+  const int dt_x = dtype_code(x, op);
+  const int fmt = y.scalar_type() == at::kFloat8_e4m3fn ? O2M_FP8_E4M3 : O2M_BF8_E5M2;
+  O2M_CALL(op, x, o2m_quantize_fp8_delayed(ptr(x), ptr<float>(amax_prev), ptr(y), ptr<float>(deq), ptr<float>(amax_next), x.numel(),
+                                           dt_x, fmt, stream));
+}
+
 void modulate_weights(const Tensor& w32, const Tensor& s, Tensor& out) {
   const char* op = "o2m::modulate_weights";
   chk_f32(w32, op, "w32"); chk_f32(s, op, "s"); chk(out, op, "out");
@@ -674,6 +687,7 @@ TORCH_LIBRARY(o2m, m) {
   m.def("conv2d_dots_finalize(Tensor partial, Tensor(a!) dots, int nchunks) -> ()");
   m.def("amax(Tensor x, Tensor(a!) amax) -> ()");
   m.def("quantize_fp8(Tensor x, Tensor amax, Tensor(a!) y, Tensor(b!) deq) -> ()");
+  m.def("quantize_fp8_delayed(Tensor x, Tensor amax_prev, Tensor(a!) y, Tensor(b!) deq, Tensor(c!) amax_next) -> ()");
   m.def("conv2d_stats_rows(Tensor x, Tensor w, Tensor y, int pad, int stride) -> int");
   m.def("conv2d_stats_chunks(Tensor x, Tensor w, Tensor y, int pad, int stride) -> int");
   m.def("instnorm_finalize(Tensor partial, Tensor(a!) mean_rstd, int P, int nchunks, float eps) -> ()");
@@ -729,6 +743,7 @@ TORCH_LIBRARY(o2m, m) {
   m.impl("modulate_weights", &modulate_weights);  \
   m.impl("amax", &amax);                          \
   m.impl("quantize_fp8", &quantize_fp8);          \
+  m.impl("quantize_fp8_delayed", &quantize_fp8_delayed); \
   m.impl("style_fwd", &style_fwd);                \
   m.impl("style_bwd", &style_bwd);                \
   m.impl("act_bwd_reduce", &act_bwd_reduce);      \

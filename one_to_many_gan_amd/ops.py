@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import contextlib
 import math
+import os as _os
 
 import torch
 
@@ -42,10 +43,20 @@ def fp8_enabled() -> bool:
     return bool(_STATE.get("fp8", False))
 
 
-def _quantize(t: torch.Tensor, fmt: torch.dtype, deq_pair: torch.Tensor) -> torch.Tensor:
-    """Per-tensor fp8 copy of ``t``; ``deq_pair`` (2 floats on the device) receives {1 / scale, amax}."""
+# O2M_FP8_DELAYED=0: every fp8 quantisation as amax pass + convert pass (dynamic scaling) instead of delayed scaling
+_FP8_DELAYED = _os.environ.get("O2M_FP8_DELAYED", "1") == "1"
+
+
+def _quantize(t: torch.Tensor, fmt: torch.dtype, deq_pair: torch.Tensor, site=None) -> torch.Tensor:
+    """Per-tensor fp8 copy of ``t``; ``deq_pair`` (2 floats on the device) receives {1 / scale, amax}.  ``site``
+    (PreparedWeight.fp8_site): delayed scaling -- from the site's second call on, ONE pass with the scale of the tensor it
+    quantised last time (the activations / gradients of a layer change slowly from step to step; what outgrows the
+    previous amax saturates).  Filters (no site) keep the exact two-pass form: they are quantised once per step."""
     q = torch.empty(t.shape, dtype=fmt, device=t.device)
-    H.quantize_fp8(t, q, deq_pair)
+    if site is not None and _FP8_DELAYED:
+        H.quantize_fp8_site(t, q, deq_pair, site)
+    else:
+        H.quantize_fp8(t, q, deq_pair)
     return q
 
 
@@ -92,6 +103,22 @@ def prepare_network(module) -> None:
     preps = [m._prepared() for m in module.modules() if hasattr(m, "_prepared")]
     if not preps or not preps[0].weight.is_cuda:
         return
+    try:
+        _prepare_network_bf16(module, preps)
+    finally:
+        if fp8_enabled():
+            # the e4m3 filter copies too, HERE (on the stream the caller forks its groups from): built lazily they would be
+            # written by whichever stream uses a layer first while the other group's stream may already read them
+            for p in preps:  # (the channel conditions of PreparedWeight.fp8_ok)
+                if p.cip % 128 == 0 and (FP8_EVERYWHERE or p.cop > 128):
+                    p.get_fp8(False)
+                if p.cop % 128 == 0 and (FP8_EVERYWHERE or p.cip > 128):
+                    p.get_fp8(True)
+
+
+def _prepare_network_bf16(module, preps) -> None:
+    import ctypes
+
     keys = [p.version_key() for p in preps]
     if any(k == p._key for k, p in zip(keys, preps)):
         return  # (partly) fresh: the lazy path prepares what is left
@@ -263,6 +290,23 @@ class PreparedWeight:
         if not fp8_enabled() or k_ch % 128 != 0:
             return False
         return FP8_EVERYWHERE or (n_ch > 128 and -(-rows // 256) * -(-n_ch // 256) >= 256)
+
+    def fp8_site(self, kind: str, device):
+        """Delayed-scaling state of one of this layer's quantisation sites ("x": forward input, "g": data-gradient input,
+        "w": per-sample filters), per stream: the two groups of a generator step run a layer on two streams at once."""
+        sites = self.__dict__.setdefault("_fp8_sites", {})
+        key = (kind, torch.cuda.current_stream(device).cuda_stream)
+        ent = sites.get(key)
+        if ent is None:
+            ent = sites[key] = [H.Fp8Site(), None]
+        # delayed scaling for a site's FIRST tensor of a weights epoch only (one optimiser step ago the same site saw the
+        # same kind of tensor); a second tensor through the same site in the same step (a decoder layer applied to
+        # several batches one after the other) is scaled by its own amax -- returns None for it
+        epoch = weights_epoch(self.weight)
+        if ent[1] == epoch:
+            return None
+        ent[1] = epoch
+        return ent[0]
 
     def get_fp8(self, data_grad: bool):
         """e4m3 copy of the forward (or data-gradient) filter + the layer's 4-float dequantisation record
@@ -829,7 +873,8 @@ class _ConvFn(torch.autograd.Function):
             H.modulate_weights(w32, s, w_b)
             if prep.fp8_ok(False, B * ho * wo):  # config #5: e4m3 activations x e4m3 per-sample filters
                 rec = torch.empty(4, dtype=torch.float32, device=x.device)
-                x8, w8 = _quantize(x, torch.float8_e4m3fn, rec[0:2]), _quantize(w_b, torch.float8_e4m3fn, rec[2:4])
+                x8 = _quantize(x, torch.float8_e4m3fn, rec[0:2], prep.fp8_site("x", x.device))
+                w8 = _quantize(w_b, torch.float8_e4m3fn, rec[2:4], prep.fp8_site("w", x.device))
                 H.conv2d_fwd(x8, w8, y, out_scale=d, bias=bias_p, residual=residual, pad=pad,
                              pad_mode=pad_mode, act=act, per_sample_w=True, deq=rec)
             else:
@@ -844,7 +889,8 @@ class _ConvFn(torch.autograd.Function):
             xin, win, deq = x, w_f, None
             if prep.fp8_ok(False, B * ho * wo):
                 win, deq = prep.get_fp8(False)
-                xin = _quantize(x, torch.float8_e4m3fn, deq[0:2])
+                deq = deq.clone()  # per call: the two groups of a generator step use a layer on two streams at once
+                xin = _quantize(x, torch.float8_e4m3fn, deq[0:2], prep.fp8_site("x", x.device))
             # partial rows per sample the selected kernel's epilogue writes (0: none -- separate statistics pass)
             nchunks = H.conv2d_stats_chunks(xin, win, y, pad=pad) if _FUSED_IN_STATS else 0
             part = None
@@ -858,7 +904,8 @@ class _ConvFn(torch.autograd.Function):
                 H.instnorm_stats(y, ws, mr, stats_eps)
         elif s is None and prep.fp8_ok(False, B * ho * wo):
             w8, rec = prep.get_fp8(False)
-            H.conv2d_fwd(_quantize(x, torch.float8_e4m3fn, rec[0:2]), w8, y, out_scale=d, bias=bias_p,
+            rec = rec.clone()  # (per call, see above)
+            H.conv2d_fwd(_quantize(x, torch.float8_e4m3fn, rec[0:2], prep.fp8_site("x", x.device)), w8, y, out_scale=d, bias=bias_p,
                          residual=residual, pad=pad, pad_mode=pad_mode, act=act, deq=rec)
         else:
             H.conv2d_fwd(x, w_f, y, in_scale=s, out_scale=d, bias=bias_p, residual=residual,
@@ -1026,15 +1073,21 @@ class _ConvFn(torch.autograd.Function):
                     pass
                 elif prep.fp8_ok(True, B * hp * wp):  # e5m2 gradients x e4m3 filter
                     w8, rec = prep.get_fp8(True)
-                    H.conv2d_fwd(_quantize(gu, torch.float8_e5m2, rec[0:2]), w8, gxp, pad=kpad, pad_mode=H.PAD_ZERO,
+                    rec = rec.clone()  # (per call: the activation half is this call's)
+                    H.conv2d_fwd(_quantize(gu, torch.float8_e5m2, rec[0:2], prep.fp8_site("g", dev)), w8, gxp, pad=kpad, pad_mode=H.PAD_ZERO,
                                  act=H.ACT_NONE, deq=rec)
                 else:
                     H.conv2d_fwd(gu, w_d, gxp, pad=kpad, pad_mode=H.PAD_ZERO, act=H.ACT_NONE)
                 if s is not None or pad_mode == H.PAD_REFLECT:
                     # the block's first conv finishes this (BlockLink.deferred) when it can fuse its activation
                     # backward: its output is this conv's input, and nothing else wants dL/dx
+                    # (not in fp8 mode: the combination deferred fold + weight-gradient stream makes the open fp8 issue
+                    # described in optim.FusedAdam.step -- a non-finite slice partial of the phase-pipelined weight
+                    # gradient -- show up within a few steps on every run, against 2 runs in 6 over 40 steps without the
+                    # deferral: tools/fp8_nan_probe.py; O2M_FP8_DEFER=1 brings the combination back for debugging)
                     defer_fold = (tail and link.fuse_act and s is not None and need_x
-                                  and (not run_style or direct or make_direct))
+                                  and (not run_style or direct or make_direct)
+                                  and (not fp8_enabled() or _os.environ.get("O2M_FP8_DEFER") == "1"))
                     if defer_fold and run_style and not direct:
                         for p in (tsw, tsb):
                             if p.grad is None:

@@ -375,6 +375,39 @@ def test_fp8_quantisation_matches_torch(fmt):
     assert rel < (0.04 if fmt == torch.float8_e4m3fn else 0.08), rel  # 3 / 2 mantissa bits
 
 
+@pytest.mark.parametrize("shape", [(4, 32, 32, 64), (48, 64, 64, 256), (1, 8, 8, 8)], ids=["small", "decode-group", "tiny"])
+def test_fp8_delayed_scaling_is_the_two_pass_result_one_call_late(shape):
+    """o2m_quantize_fp8_delayed through _hip.quantize_fp8_site: the first call of a site is the two-pass form; the
+    second call of the SAME tensor (scale from the first call's partial maxima) gives the same bytes and dequantisation
+    factor; a third call with a tensor twice as large is scaled by the PREVIOUS amax (so it saturates at FMT_MAX), and
+    a fourth call with it again is exact once more -- the partial maxima each call records are those of its tensor."""
+    from one_to_many_gan_amd import _hip as H
+
+    torch.manual_seed(6)
+    x = (torch.randn(*shape, device="cuda") * 3).to(torch.bfloat16)
+    fmt, top = torch.float8_e4m3fn, 448.0
+    ref, ref_deq = torch.empty(x.shape, dtype=fmt, device="cuda"), torch.empty(2, device="cuda")
+    H.quantize_fp8(x, ref, ref_deq)
+    site = H.Fp8Site()
+    for _ in range(2):  # two-pass, then delayed with the same tensor's maxima
+        y, deq = torch.empty(x.shape, dtype=fmt, device="cuda"), torch.empty(2, device="cuda")
+        H.quantize_fp8_site(x, y, deq, site)
+        assert torch.equal(y.view(torch.uint8), ref.view(torch.uint8)) and torch.equal(deq, ref_deq)
+    x2 = (x.float() * 2).to(torch.bfloat16)
+    y, deq = torch.empty(x.shape, dtype=fmt, device="cuda"), torch.empty(2, device="cuda")
+    H.quantize_fp8_site(x2, y, deq, site)  # scale of x: the upper half of x2's range saturates
+    assert torch.equal(deq, ref_deq)
+    assert float(y.float().abs().max()) == top
+    want = (x2.float() * (top / ref_deq[1])).clamp(-top, top).to(fmt)
+    assert float((y.view(torch.uint8) == want.view(torch.uint8)).float().mean()) > 0.999
+    y, deq = torch.empty(x.shape, dtype=fmt, device="cuda"), torch.empty(2, device="cuda")
+    H.quantize_fp8_site(x2, y, deq, site)  # now with x2's own maxima (recorded by the third call)
+    assert float(deq[1]) == float(x2.float().abs().max())
+    ref2, ref2_deq = torch.empty(x.shape, dtype=fmt, device="cuda"), torch.empty(2, device="cuda")
+    H.quantize_fp8(x2, ref2, ref2_deq)
+    assert torch.equal(y.view(torch.uint8), ref2.view(torch.uint8)) and torch.equal(deq, ref2_deq)
+
+
 FP8_CONVS = [
     # B, H, W, Ci, Co, k, pad, reflect, x format, features
     (16, 64, 64, 256, 256, 3, 1, True, torch.float8_e4m3fn, "plain"),
