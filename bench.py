@@ -258,20 +258,40 @@ def count_dispatches(trainer):
     return {"o2m_ops": n["o2m"], "aten_ops": n["aten"], "note": "operator dispatches of one D+G step"}
 
 
-def extra_leg(args, device, precision, size, batch, steps=5, warmup=2):
+def settle(tr, device, warmup, rounds=4):
+    """Warm-up of a side leg: blocks of ``warmup`` un-synchronised steps (the host runs ahead exactly as in the timed
+    steps) until a block needs no new device allocation, at most ``rounds`` blocks: with the host several steps ahead
+    the caching allocator keeps growing its pool for a while, and a hipMalloc inside the timed steps can cost anything
+    (249 / 495 ms per step were read this way on a busy host).  Returns the number of warm-up steps run."""
+    n = 0
+    for _ in range(rounds):
+        before = torch.cuda.memory_stats(device).get("num_device_alloc", 0)
+        for _ in range(warmup):
+            tr.step()
+        n += warmup
+        torch.cuda.synchronize()
+        if torch.cuda.memory_stats(device).get("num_device_alloc", 0) == before:
+            break
+    return n
+
+
+def extra_leg(args, device, precision, size, batch, steps=6, warmup=3):
     """One more configuration timed in the same run (BASELINE configs #4 and #5), a few steps each."""
     cfg = make_config(size, args.channels, batch)
     tr = Trainer(product_namespace(precision), cfg, device)
-    for _ in range(warmup):
-        tr.step()
-    torch.cuda.synchronize()
+    warmup = settle(tr, device, max(warmup, steps))  # (blocks as long as the timed region: the same host lead, the same pool)
+    mallocs = torch.cuda.memory_stats(device).get("num_device_alloc", 0)
     t0 = time.perf_counter()
     for _ in range(steps):
         tr.step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     out = {"workload": f"{size}x{size}x{args.channels}, batch {batch}, {precision}", "ms_per_step": round(dt * 1e3, 3),
-           "value": round(batch / dt, 3), "unit": "images/sec", "steps": steps, "warmup": warmup}
+           "value": round(batch / dt, 3), "unit": "images/sec", "steps": steps, "warmup": warmup,
+           # (hipMalloc calls inside the timed steps: a leg that is still growing its memory pool reads slow)
+           "device_allocs_in_timed_steps": torch.cuda.memory_stats(device).get("num_device_alloc", 0) - mallocs,
+           "reserved_gib": round(torch.cuda.max_memory_reserved(device) / 2**30, 1),
+           "alloc_retries": torch.cuda.memory_stats(device).get("num_alloc_retries", 0)}
     flop = FLOP_PER_IMAGE_STEP.get((size, args.channels))
     if flop:
         out["step_mfma_frac"] = round(batch / dt * flop / MFMA_PEAK[precision], 4)
@@ -336,24 +356,26 @@ def graph_mode_leg(device, size=64, channels=1, batch=4, steps=20):
     return out
 
 
-def parity_mode_leg(args, device, steps=5, warmup=2):
+def parity_mode_leg(args, device, steps=6, warmup=3):
     """The SAME workload in the precision that meets the 1e-3 parity gate (fp32 storage, bf16x3 split
     MFMA), timed in this run so that the gate-passing throughput is driver-measured too."""
     cfg = make_config(args.size, args.channels, args.batch)
     tr = Trainer(product_namespace("fp32"), cfg, device)
-    for _ in range(warmup):
-        tr.step()
-    torch.cuda.synchronize()
+    warmup = settle(tr, device, max(warmup, steps))  # (blocks as long as the timed region: the same host lead, the same pool)
+    mallocs = torch.cuda.memory_stats(device).get("num_device_alloc", 0)
     t0 = time.perf_counter()
     for _ in range(steps):
         tr.step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    mallocs = torch.cuda.memory_stats(device).get("num_device_alloc", 0) - mallocs
     ips = args.batch / dt
     flop = FLOP_PER_IMAGE_STEP.get((args.size, args.channels))
     out = {"dtype": "fp32 storage, bf16x3 split MFMA (outputs within 1e-3 of the CPU reference: "
                     "tests/test_hip_parity.py)", "ms_per_step": round(dt * 1e3, 3), "value": round(ips, 3),
-           "unit": "images/sec", "steps": steps, "warmup": warmup}
+           "unit": "images/sec", "steps": steps, "warmup": warmup, "device_allocs_in_timed_steps": mallocs,
+           "reserved_gib": round(torch.cuda.max_memory_reserved(device) / 2**30, 1),
+           "alloc_retries": torch.cuda.memory_stats(device).get("num_alloc_retries", 0)}
     if flop:
         out["step_mfma_frac"] = round(ips * flop / 2.5e15, 4)
     return out
@@ -443,11 +465,13 @@ def main():
     for _ in range(args.warmup):
         trainer.step()
     fence()
+    mallocs0 = torch.cuda.memory_stats(device).get("num_device_alloc", 0)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         last = trainer.step()
     fence()
     elapsed = time.perf_counter() - t0
+    mallocs = torch.cuda.memory_stats(device).get("num_device_alloc", 0) - mallocs0
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -460,6 +484,7 @@ def main():
         "value": round(images_per_sec, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "device_allocs_in_timed_steps": mallocs,  # (hipMalloc calls of the caching allocator inside the timed steps)
         "dtype": args.precision, "data": "synthetic",
         "config": {"workload": f"{args.size}x{args.size}x{args.channels} D+G step (discriminator_step + "
                                f"generator_step), batch {args.batch}/GPU, stock config.toml hyper-parameters, "
