@@ -15,6 +15,7 @@ bounded sample of the same workload).
 from __future__ import annotations
 
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -102,7 +103,14 @@ class Trainer:
         return self._step()
 
     def _step(self):
-        """The loop body of train.py:204-251."""
+        """The loop body of train.py:204-251, at most two steps queued (ops.StepThrottle, as train.py runs it)."""
+        th = self.__dict__.get("_throttle")
+        if th is None:
+            th = self._throttle = self.ns.make_throttle(self.device)
+        with th:
+            return self._step_body()
+
+    def _step_body(self):
         # The benchmark workload holds the augmentation at p = 0 (SURVEY.md section 8d; the CPU oracle
         # has no transforms): the ADAp controller still runs inside discriminator_step, its output
         # is read like train.py:206 does, but not applied.
@@ -132,7 +140,7 @@ def product_namespace(precision, ada_p=0.0):
                            make_ada=(pk.IdentityADA if ada_p == 0 else
                                      (lambda: pk.AdaptiveDiscriminatorAugmentation(**pk.REFERENCE_ADA_SWITCHES))),
                            discriminator_step=pt.discriminator_step,
-                           generator_step=pt.generator_step)
+                           generator_step=pt.generator_step, make_throttle=pk.ops.StepThrottle)
 
 
 def oracle_namespace():
@@ -146,7 +154,8 @@ def oracle_namespace():
                            MappingNetwork=om.MappingNetwork, StyleExtractor=om.StyleExtractor,
                            make_adam=lambda net, lr, betas: torch.optim.Adam(net.parameters(), lr=lr, betas=betas),
                            ImageBuffer=ot.ImageBuffer, ADAp=ot.ADAp, make_ada=ot.IdentityADA,
-                           discriminator_step=ot.discriminator_step, generator_step=ot.generator_step)
+                           discriminator_step=ot.discriminator_step, generator_step=ot.generator_step,
+                           make_throttle=lambda device: contextlib.nullcontext())
 
 
 def kernel_profile(trainer, precision, steps=3):

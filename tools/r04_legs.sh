@@ -1,3 +1,8 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-for i in 1 2; do python bench.py --no-cpu-baseline 2>/dev/null | python -c 'import sys, json; d=json.loads(sys.stdin.read()); print(d["ms_per_step"], {k: (d[k]["ms_per_step"], d[k].get("device_allocs_in_timed_steps"), d[k].get("reserved_gib"), d[k].get("alloc_retries")) for k in ("parity_mode","fp8_mode","config4")})'; done
+run() { env "$@" python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-parity-mode --no-kernel-profile --no-extra-legs 2>/dev/null | python -c 'import sys, json, torch; d=json.loads(sys.stdin.read()); print(d["ms_per_step"], "allocs in timed steps", d["device_allocs_in_timed_steps"])'; }
+for i in 1 2; do
+echo -n "in flight 3: "; run O2M_MAX_STEPS_IN_FLIGHT=3
+echo -n "in flight 2: "; run O2M_MAX_STEPS_IN_FLIGHT=2
+echo -n "unbounded:   "; run O2M_MAX_STEPS_IN_FLIGHT=0
+done
