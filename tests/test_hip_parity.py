@@ -286,6 +286,29 @@ def test_deterministic_mode_makes_training_steps_bitwise_reproducible(precision)
 
 
 @pytest.mark.gpu
+def test_discriminator_step_on_its_own_stream_gives_the_same_steps():
+    """ops.d_step_stream (round 4): discriminator_step queued on a stream of its own, the generator step that follows
+    ordered behind it only where it uses the discriminator.  Scheduling only: two D+G steps (Adam included) with and
+    without it agree to the run-to-run noise of the fp32 mode's atomically accumulated sums (the streams exist only
+    outside deterministic mode), and the overlapped run still matches the reference fixtures
+    (test_training_steps_match_reference runs with the default, i.e. with the overlap)."""
+    from one_to_many_gan_amd import ops
+
+    assert ops._D_OVERLAP, "the default configuration runs the discriminator step on its own stream"
+    with_overlap = run_case("steps64", product_ns("fp32"), "cuda")
+    assert ops._DSTREAM, "the discriminator-step stream was used"
+    ops._D_OVERLAP = False
+    try:
+        without = run_case("steps64", product_ns("fp32"), "cuda")
+    finally:
+        ops._D_OVERLAP = True
+    for k in with_overlap:
+        a, b = with_overlap[k].double(), without[k].double()
+        err = float((a - b).norm() / max(float(b.norm()), 1e-30))
+        assert err < 1e-4, (k, err)
+
+
+@pytest.mark.gpu
 def test_config4_step_at_full_size_is_finite_and_reproducible():
     """BASELINE config #4 at its real size (512 x 512 RGB, batch 8, bf16: 3 down-samplings, 512-channel latent, the
     3B = 24 decode group at 512 x 512): one D+G step through the product's step functions.  No CPU oracle finishes

@@ -269,3 +269,22 @@ def test_device_resident_controller_and_history_pool_follow_the_reference_rules(
     assert 0.3 < swapped / total < 0.7
     with pytest.raises(ValueError):
         DeviceImageBuffer(0)
+
+
+def test_round4_scheduling_helpers_are_inert_without_a_gpu():
+    """ops.host_to_device / StepThrottle / d_step_stream (round 4): on CPU tensors they do nothing but pass the values
+    through -- the gloo rehearsals and the CPU-side checks run the same step functions."""
+    import torch
+
+    from one_to_many_gan_amd import ops
+
+    t = torch.rand(5)
+    assert torch.equal(ops.host_to_device(t, "cpu"), t)
+    th = ops.StepThrottle("cpu")
+    for _ in range(4):
+        with th:
+            pass
+    assert th.queue == []
+    assert ops.d_step_stream(torch.device("cpu")) is None
+    ops.d_step_mark(torch.device("cpu"), "done")  # no-ops
+    ops.d_step_wait(torch.device("cpu"), "done")
