@@ -274,7 +274,10 @@ def _batched_decodes(config, device, generator, discriminator, mapping_network, 
     ``t_lat``: internal [2B, h, w, C] latents, chunk 0 = shoeprints, chunk 1 = shoemarks."""
     batch, lam, blocks = config["training"]["batch_size"], config["optimisation"], generator.n_style_blocks
     # Every style vector first, in the reference's draw order (builder.py:115-128, training.py:214-223:
-    # get_single_w(1) -> theta -> h -> get_two_w; get_single_w(0) and the style extractor draw nothing) ...
+    # get_single_w(1) -> theta -> h -> get_two_w; get_single_w(0) and the style extractor draw nothing).  With the
+    # augmentation ON (p > 0) ``ada(generated)`` draws from the CPU generator too, and here it runs AFTER theta and
+    # get_two_w, while the reference (and _separate_decodes) has it between get_single_w(1) and theta: the batched form
+    # reorders the CPU draws then (statistically harmless; the benchmark and the parity cases hold p at 0).
     side = ops.group_stream(device)
 
     def draw_styles():

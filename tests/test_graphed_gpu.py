@@ -90,6 +90,9 @@ def test_train_loop_with_the_graphed_step_logs_checkpoints_and_resumes(tmp_path)
     ref_p, ref_buf = ADAp(1, 0.0, 1, 0.6), ImageBuffer(4)
     first = load_checkpoint(ck, dev, nets["G"], nets["D"], nets["M"], nets["S"], ada_p=ref_p, image_buffer=ref_buf)
     assert first == 8 and ref_buf.num_imgs == 4 and ref_buf.images[0].shape == (1, 1, 64, 64)
+    # the augmentation was held at the identity: the checkpoint carries the p the run started from, not what the
+    # device controller integrated without feedback
+    assert float(ref_p.p) == 0.0 and any("ADA probability held at 0" in l for l in lines)
     # ... and the graphed loop resumes from it
     lines2 = []
     _, opts2 = train.run(cfg, dev, 10, train.synthetic_batches(30, cfg, dev), train.synthetic_batches(40, cfg, dev),

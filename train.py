@@ -169,8 +169,8 @@ def _run_graphed(config, device, steps, shoeprint_iter, shoemark_iter, resume, l
     o2m.ops.set_deterministic(bool(config["training"].get("deterministic_cuda_kernels", False)))
     nets, opts = build(config, device)
     gs = GraphedStep(config, device, nets, opts, shoeprint_iter, shoemark_iter, o2m.IdentityADA())
-    log("graphed step: augmentation held at the identity (p = 0); style draws, history pool and ADAp on the device")
-    first = 0
+    log("graphed step: augmentation held at the identity; style draws, history pool and ADAp on the device")
+    first, p_held = 0, 0.0
     if resume:
         ref_p = ADAp(1, 0.0, 1, config["ada"]["discriminator_real_acc_target"])
         ref_buf = ImageBuffer(config["training"]["image_buffer_size"])
@@ -178,7 +178,13 @@ def _run_graphed(config, device, steps, shoeprint_iter, shoemark_iter, resume, l
                                 opts["M"], opts["S"], ref_p, ref_buf)
         gs.ada_p.load_reference(ref_p)
         gs.buffer.load_reference(ref_buf, device)
+        p_held = float(ref_p.p)
         log(f"resumed from {resume} at step {first}")
+    # The device controller keeps integrating the discriminator's confidence, but no augmentation feeds back: its p only
+    # drifts up (1.18 after 600 steps, profiles/r03_long_run.txt).  That drift is NOT what this run trained with: the log
+    # line and the checkpoints carry the p the run started from (an eager resume, or the reference itself, would otherwise
+    # start augmenting at the drifted value).
+    log(f"graphed step: ADA probability held at {p_held:g} in the log and the checkpoints (the controller's own value is not used)")
     logger = Logger(steps)
     ev = config["evaluation"]
     t0 = time.perf_counter()
@@ -187,7 +193,7 @@ def _run_graphed(config, device, steps, shoeprint_iter, shoemark_iter, resume, l
         last = step + 1 == steps
         if (step + 1) % ev["log_interval"] == 0 or last:
             (d_loss, real_acc, fake_acc), g_vals = gs.logged_means()  # window means, summed on the device
-            logger.log_ada_ps.append(gs.ada_p.value())
+            logger.log_ada_ps.append(p_held)
             logger.log_total_disc_losses.append(d_loss)
             logger.log_disc_real_accs.append(real_acc)
             logger.log_disc_fake_accs.append(fake_acc)
@@ -211,8 +217,10 @@ def _run_graphed(config, device, steps, shoeprint_iter, shoemark_iter, resume, l
                                              nets["G"], nets["S"])
                 nets["M"].device_draws = draws
                 log(f"image grids {grids[0]} {grids[1]}")
+            ref_p_out = gs.ada_p.to_reference()
+            ref_p_out.p = torch.tensor(p_held)
             path_ = model_checkpoint(step, config, nets["G"], nets["D"], nets["M"], nets["S"], opts["G"], opts["D"],
-                                     opts["M"], opts["S"], gs.ada_p.to_reference(), gs.buffer.to_reference())
+                                     opts["M"], opts["S"], ref_p_out, gs.buffer.to_reference())
             log(f"checkpoint {path_}")
             for k in ("G", "M", "S"):
                 nets[k].train()
