@@ -222,6 +222,9 @@ def _discriminator_step(config, device, discriminator, generator, mapping_networ
 
     loss.backward()
     discriminator_optimiser.step()
+    # the updated discriminator's filter forms here, on this step's stream: the generator step then finds them fresh when
+    # it reaches its adversarial term (_await_discriminator) instead of building them on its own critical path
+    ops.prepare_network(discriminator)
     out = _floats(loss, sign_real, sign_fake)
     return out[0], (out[1], out[2])
 
