@@ -14,7 +14,7 @@ size = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 batch = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 graph = "--graph" in sys.argv
 dev = torch.device("cuda:0")
-o2m.set_precision("bf16")
+o2m.set_precision(os.environ.get("LONG_RUN_PRECISION", "bf16"))
 cfg = make_config(3 if size > 64 else 1, (size, size), batch)
 cfg["training"].update(checkpoint_directory=Path(tempfile.mkdtemp()), training_run="long", training_steps=steps)
 cfg["evaluation"] = {"log_interval": 50, "checkpoint_interval": 10 ** 9, "n_evaluation_images": 0, "inference_batch_size": 2}
