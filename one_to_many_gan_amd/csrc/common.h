@@ -118,14 +118,17 @@ __device__ __forceinline__ void atomic_add8(float* p, const float (&v)[8]) {
 // Streaming variants chosen at run time (block-uniform flag): tensors of >= 64 MiB that a kernel touches once.
 // Read or written normally they only push the lines the concurrent MFMA kernels re-read out of L2.
 constexpr size_t kStreamBytes = (size_t)64 << 20;
+#ifndef O2M_NO_STREAMING
+#define O2M_NO_STREAMING 0  // (1: every streaming load / store becomes a plain one -- A/B builds, tools/build_variant.sh)
+#endif
 template <typename T>
 __device__ __forceinline__ void load8x(const T* p, float (&v)[8], bool stream) {
-  if (stream) load8_stream(p, v);
+  if (stream && !O2M_NO_STREAMING) load8_stream(p, v);
   else load8(p, v);
 }
 template <typename T>
 __device__ __forceinline__ void store8x(T* p, const float (&v)[8], bool stream) {
-  if (stream) store8_stream(p, v);
+  if (stream && !O2M_NO_STREAMING) store8_stream(p, v);
   else store8(p, v);
 }
 

@@ -645,7 +645,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_kernel(c
         for (int q = 0; q < 8; ++q) o[q] += rv[q];
       }
       if (FOLD && f_atomic) atomic_add8(Y + off, o);
-      else if (stream_out) store8_stream(Y + off, o);
+      else if (stream_out && !O2M_NO_STREAMING) store8_stream(Y + off, o);
       else store8(Y + off, o);
     }
     if (d.stats && mbase < M) {  // (a tile's trailing passes can lie past the problem: nothing to report)

@@ -9,6 +9,8 @@ one memset, and (c) data-parallel training all-reduces one contiguous bucket per
 
 from __future__ import annotations
 
+import os as _os
+
 import torch
 
 from . import _hip as H
@@ -73,7 +75,7 @@ class FusedAdam:
         for hook in self.pre_step_hooks:
             hook()
         self.step_t += 1
-        if ops.fp8_enabled() and self.bucket.grad.is_cuda:
+        if ops.fp8_enabled() and self.bucket.grad.is_cuda and _os.environ.get("O2M_FP8_NAN_GUARD", "1") != "0":
             # fp8 mode only (config #5; the bf16 / fp32 paths never take this branch): non-finite gradient entries are
             # dropped for this step, the way mixed-precision training skips what its loss scale cannot represent.  Besides
             # genuine e5m2 saturation there is an OPEN issue behind it: with several streams the phase-pipelined weight
